@@ -1,0 +1,208 @@
+"""Pins the CPU oracle (oracle/) against vectors captured from the reference (tools/make_golden.py).
+
+The reference holds no tests or fixtures of its own; these goldens are outputs of
+the reference itself, run in the build container.  Tolerances: the oracle issues the same ATen
+calls in almost the same order, so fp32 agreement is ~1e-6 relative; bounds below leave a small
+margin for einsum/rearrange re-association and thread-count effects.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from oracle import unet_ref
+from oracle.weightgen import synth_tensor
+from conftest import GOLDEN, max_abs, synth_input
+
+
+def _sd(prefix, shapes):
+    return {k: synth_tensor(prefix + k if not k.startswith(prefix) else k, s) for k, s in shapes.items()}
+
+
+# ------------------------------------------------------------------ layout / construction KATs
+def test_layout_matches_reference_state_dict():
+    lay = json.load(open(os.path.join(GOLDEN, "layout_kat.json")))
+    for tag in ("small@256", "small@128", "small@64", "large@256", "large@64"):
+        variant, size = tag.split("@")
+        shapes = oracle.param_shapes(oracle.make_spec(variant, int(size)), prefix="")
+        ref = [(k, tuple(s)) for k, s in lay[tag]["keys"]]
+        assert list(shapes.items()) == ref, tag
+        assert sum(int(np.prod(s)) for s in shapes.values()) == lay[tag]["num_params"]
+    assert len(lay["small@256"]["keys"]) == 321 and lay["small@256"]["num_params"] == 18008035
+    assert len(lay["small@128"]["keys"]) == 351 and len(lay["small@64"]["keys"]) == 381
+    assert lay["large@256"]["num_params"] == 86809155
+
+
+def test_tiny_base_unconstructible_like_reference():
+    lay = json.load(open(os.path.join(GOLDEN, "layout_kat.json")))
+    for v in ("tiny", "base"):
+        assert lay[f"{v}@256"]["error"] == "ValueError"
+        with pytest.raises(ValueError):
+            oracle.param_shapes(oracle.make_spec(v, 256))
+    assert lay["unknown_variant"]["error"] == "ValueError"
+    with pytest.raises(ValueError):
+        oracle.make_spec("huge")
+
+
+# ------------------------------------------------------------------ scheduler KATs
+def test_scheduler_tables_and_timesteps(golden):
+    g = golden("scheduler_kat.npz")
+    tab = oracle.LCMTables.build()
+    assert np.array_equal(tab.alphas_cumprod.numpy(), g["alphas_cumprod"])  # bit-exact fp32 table
+    assert np.array_equal(oracle.LCMTables.build(rescale_betas_zero_snr=False).alphas_cumprod.numpy(),
+                          g["alphas_cumprod_norescale"])
+    assert oracle.lcm_timesteps(4) == [739, 499, 259, 19] == g["timesteps_4"].tolist()
+    assert oracle.lcm_timesteps(6) == g["timesteps_6"].tolist() == [819, 659, 499, 339, 179, 19]
+    assert oracle.lcm_timesteps(8) == g["timesteps_8"].tolist()
+    # SURVEY.md 8a-a2 probe values
+    a = tab.alphas_cumprod
+    for t, v in [(19, 0.981010377), (259, 0.636815190), (499, 0.242358997), (739, 0.037058491), (0, 0.999149978)]:
+        assert abs(a[t].item() - v) < 5e-9
+    assert a[999].item() == 0.0
+
+
+@pytest.mark.parametrize("ptype", ["epsilon", "v_prediction"])
+def test_scheduler_step(golden, ptype):
+    g = golden("scheduler_kat.npz")
+    tab = oracle.LCMTables.build(prediction_type=ptype)
+    ts = oracle.lcm_timesteps(4)
+    sample = synth_input("sched.sample", (2, 3, 8, 8), -3, 3)
+    mo = synth_input("sched.model_output", (2, 3, 8, 8), -2, 2)
+    for i, t in enumerate(ts):
+        prev_t = ts[i + 1] if i + 1 < len(ts) else 0
+        torch.manual_seed(1000 + t)
+        noise = torch.randn_like(sample) if prev_t else None
+        prev, x0 = oracle.lcm_step(tab, mo, t, prev_t, sample, noise)
+        assert np.array_equal(x0.numpy(), g[f"step_{ptype}_{t}_x0"])
+        assert np.array_equal(prev.numpy(), g[f"step_{ptype}_{t}_prev"])
+
+
+def test_add_noise_velocity(golden):
+    g = golden("scheduler_kat.npz")
+    tab = oracle.LCMTables.build()
+    tt = torch.tensor([0, 19, 499, 999])
+    x0 = synth_input("sched.x0", (4, 3, 8, 8)); nz = synth_input("sched.noise", (4, 3, 8, 8), -2, 2)
+    assert np.array_equal(oracle.add_noise(tab, x0, nz, tt).numpy(), g["add_noise"])
+    assert np.array_equal(oracle.get_velocity(tab, x0, nz, tt).numpy(), g["get_velocity"])
+
+
+# ------------------------------------------------------------------ per-op KATs
+def test_sinusoidal_embedding(golden):
+    g = golden("ops_kat.npz")
+    e = oracle.sinusoidal_embedding(torch.from_numpy(g["sinemb32_t"]), 32)
+    assert max_abs(e, g["sinemb32"]) < 1e-6
+
+
+@pytest.mark.parametrize("name,cin,cout", [("irb_32_32", 32, 32), ("irb_32_64", 32, 64), ("irb_96_32", 96, 32)])
+def test_irb(golden, name, cin, cout):
+    g = golden("ops_kat.npz")
+    spec = oracle.UNetSpec()
+    shapes = {k[len("unet.encoder_blocks.0.0."):]: s for k, s in oracle.param_shapes(spec).items()
+              if k.startswith("unet.encoder_blocks.0.0.")}
+    hid = cin * 4
+    shapes.update({"norm1.weight": (cin,), "norm1.bias": (cin,), "norm2.weight": (hid,), "norm2.bias": (hid,),
+                   "expand.weight": (hid, cin, 1, 1), "depthwise.weight": (hid, 1, 3, 3),
+                   "se.fc1.weight": (hid // 4, hid, 1, 1), "se.fc1.bias": (hid // 4,),
+                   "se.fc2.weight": (hid, hid // 4, 1, 1), "se.fc2.bias": (hid,),
+                   "project.weight": (cout, hid, 1, 1), "time_mlp.1.weight": (2 * hid, 128), "time_mlp.1.bias": (2 * hid,)})
+    if cin != cout:
+        shapes["skip.weight"] = (cout, cin, 1, 1)
+    sd = {name + "." + k: synth_tensor(name + "." + k, s) for k, s in shapes.items()}
+    x = synth_input(name + ".x", (2, cin, 16, 16), -2, 2)
+    te = synth_input(name + ".temb", (2, 128), -1, 1)
+    y = unet_ref.irb_forward(sd, name, x, te)
+    assert max_abs(y, g[name]) < 2e-5 * max(1.0, np.abs(g[name]).max())
+
+
+def test_se(golden):
+    g = golden("ops_kat.npz")
+    shapes = {"fc1.weight": (32, 128, 1, 1), "fc1.bias": (32,), "fc2.weight": (128, 32, 1, 1), "fc2.bias": (128,)}
+    sd = {"se128." + k: synth_tensor("se128." + k, s) for k, s in shapes.items()}
+    x = synth_input("se128.x", (2, 128, 8, 8), -2, 2)
+    assert max_abs(x * unet_ref.se_gate(sd, "se128", x), g["se128"]) < 1e-6
+
+
+@pytest.mark.parametrize("name,c,hw", [("attn256_8", 256, 8), ("attn256_16", 256, 16), ("attn64_8", 64, 8)])
+def test_linear_attention(golden, name, c, hw):
+    g = golden("ops_kat.npz")
+    shapes = {"norm.weight": (c,), "norm.bias": (c,), "to_qkv.weight": (384, c, 1, 1),
+              "to_out.0.weight": (c, 128, 1, 1), "to_out.1.weight": (c,), "to_out.1.bias": (c,)}
+    sd = {name + "." + k: synth_tensor(name + "." + k, s) for k, s in shapes.items()}
+    y = unet_ref.linear_attention_forward(sd, name, synth_input(name + ".x", (2, c, hw, hw), -2, 2), 4)
+    assert max_abs(y, g[name]) < 2e-5
+
+
+def test_down_up(golden):
+    g = golden("ops_kat.npz")
+    sd = {"down32.down.weight": synth_tensor("down32.down.weight", (32, 32, 3, 3)),
+          "down32.down.bias": synth_tensor("down32.down.bias", (32,)),
+          "up64.conv.weight": synth_tensor("up64.conv.weight", (64, 64, 3, 3)),
+          "up64.conv.bias": synth_tensor("up64.conv.bias", (64,))}
+    assert max_abs(unet_ref.downsample(sd, "down32", synth_input("down32.x", (2, 32, 16, 16), -2, 2)), g["down32"]) < 1e-5
+    assert max_abs(unet_ref.upsample(sd, "up64", synth_input("up64.x", (2, 64, 8, 8), -2, 2)), g["up64"]) < 1e-5
+
+
+# ------------------------------------------------------------------ whole UNet + enhance loop
+@pytest.mark.parametrize("tag,variant,size,batch", [("small64", "small", 64, 2), ("small128", "small", 128, 1),
+                                                     ("large64", "large", 64, 1)])
+def test_unet_forward(golden, tag, variant, size, batch):
+    g = golden("unet_kat.npz")
+    spec = oracle.make_spec(variant, size)
+    sd = oracle.synth_state_dict(oracle.param_shapes(spec))
+    x = synth_input(tag + ".x", (batch, 6, size, size), -1.5, 1.5)
+    with torch.no_grad():
+        y = oracle.unet_forward(sd, spec, x, torch.from_numpy(g[tag + "_t"]))
+    assert max_abs(y, g[tag]) < 5e-5 * max(1.0, np.abs(g[tag]).max())
+
+
+def test_enhance_small64(golden):
+    g = golden("enhance_small64.npz")
+    spec = oracle.make_spec("small", 64)
+    sd = oracle.synth_state_dict(oracle.param_shapes(spec))
+    low = synth_input("e2e64.low", (2, 3, 64, 64), -1.0, -0.4)
+    # reference draw order on the *global* generator seeded with 123 (tools/make_golden.py)
+    torch.manual_seed(int(g["seed"][0]))
+    noise = [torch.randn(2, 3, 64, 64) for _ in range(4)]
+    out = oracle.enhance_ref(sd, spec, low, 4, noise)
+    for i in range(4):
+        ref = g[f"latents_{i}"]
+        assert max_abs(out["noise_pred"][i], g[f"noise_pred_{i}"]) < 1e-4 * max(1.0, np.abs(g[f"noise_pred_{i}"]).max())
+        assert max_abs(out["intermediate"][i], ref) < 1e-4 * max(1.0, np.abs(ref).max())
+    assert max_abs(out["enhanced"], g["enhanced"]) < 1e-4
+    # training branch: add_noise -> cat -> unet (low_light_diffusion.py:140-171)
+    tab = oracle.LCMTables.build()
+    normal = synth_input("e2e64.normal", (2, 3, 64, 64), -1, 1)
+    tr_noise = synth_input("e2e64.train_noise", (2, 3, 64, 64), -2, 2)
+    t = torch.tensor([500, 37])
+    with torch.no_grad():
+        pred = oracle.unet_forward(sd, spec, torch.cat([oracle.add_noise(tab, normal, tr_noise, t), low], 1), t)
+    assert max_abs(pred, g["train_noise_pred"]) < 5e-5 * max(1.0, np.abs(g["train_noise_pred"]).max())
+
+
+def test_enhance_small256_samples(golden):
+    """BASELINE config-2 shape (B=1): strided samples, corner crops and moments of every step."""
+    g = golden("enhance_small256.npz")
+    spec = oracle.make_spec("small", 256)
+    sd = oracle.synth_state_dict(oracle.param_shapes(spec))
+    low = synth_input("e2e256.low", (1, 3, 256, 256), -1.0, -0.4)
+    torch.manual_seed(123)
+    noise = [torch.randn(1, 3, 256, 256) for _ in range(4)]
+    out = oracle.enhance_ref(sd, spec, low, 4, noise)
+
+    def check(tag, z):
+        scale = max(1.0, float(g[tag + "_mom"][2]))
+        tol = 1e-4 * scale
+        assert max_abs(z[:, :, ::8, ::8], g[tag + "_s8"]) < tol
+        assert max_abs(z[:, :, :16, :16], g[tag + "_c00"]) < tol
+        assert max_abs(z[:, :, -16:, -16:], g[tag + "_c11"]) < tol
+        assert max_abs(z[:, :, :16, -16:], g[tag + "_c01"]) < tol
+        assert max_abs(z[:, :, -16:, :16], g[tag + "_c10"]) < tol
+        assert abs(z.double().mean().item() - g[tag + "_mom"][0]) < tol
+
+    for i in range(4):
+        check(f"noise_pred_{i}", out["noise_pred"][i])
+        check(f"latents_{i}", out["intermediate"][i])
+    check("enhanced", out["enhanced"])
