@@ -1,0 +1,23 @@
+"""MI355X-native engine for the LCM denoising hot path of zamazincode/cv-diffusion-model.
+
+Public names mirror `src/models/__init__.py:1-10` of the reference (LowLightDiffusion, EfficientUNet,
+EfficientUNetConfig, LCMScheduler) plus the operator classes of efficient_unet.py.  Compute lives in
+`libllie_hip.so` (hand-written HIP for gfx950, C ABI in include/llie.h); importing this package does
+not need a GPU, running anything does.
+
+The directory name contains '-', so import it as `import cv_diffusion_model_amd` (alias module at the
+repository root) or `importlib.import_module("cv-diffusion-model_amd")`.
+"""
+from .unet import (EfficientUNet, EfficientUNetConfig, create_efficient_unet, InvertedResidualBlock,
+                   LinearAttention, Downsample, Upsample)
+from .scheduler import LCMScheduler, LCMSchedulerOutput, get_lcm_timesteps
+from .pipeline import LowLightDiffusion, LowLightDiffusionOutput, normalize_image, denormalize_image
+from .sharding import shard_range, enhance_sharded, all_gather_batch
+from .build import build_library, library_path
+
+__all__ = [
+    "EfficientUNet", "EfficientUNetConfig", "create_efficient_unet", "InvertedResidualBlock", "LinearAttention",
+    "Downsample", "Upsample", "LCMScheduler", "LCMSchedulerOutput", "get_lcm_timesteps", "LowLightDiffusion",
+    "LowLightDiffusionOutput", "normalize_image", "denormalize_image", "shard_range", "enhance_sharded",
+    "all_gather_batch", "build_library", "library_path",
+]

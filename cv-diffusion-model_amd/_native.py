@@ -1,0 +1,163 @@
+"""ctypes binding of libllie_hip.so (C ABI declared in include/llie.h).
+
+There is no Python/PyTorch fallback: if the library is missing the import of the engine fails loudly
+(`LibraryNotBuilt`), and if no HIP device is present every compute entry point raises.
+PyTorch is used by callers only for device memory, streams and torch.distributed.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import List, Tuple
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libllie_hip.so")
+
+# enums of include/llie.h
+LLIE_F32, LLIE_F16, LLIE_BF16 = 0, 1, 2
+LLIE_UNET, LLIE_IRB, LLIE_ATTN, LLIE_DOWN, LLIE_UP = 0, 1, 2, 3, 4
+ERR_ARG, ERR_SHAPE, ERR_CONFIG, ERR_KEY, ERR_NOT_LOADED, ERR_WORKSPACE, ERR_NO_DEVICE = -1, -2, -3, -4, -5, -6, -7
+
+EXPORTS = [
+    "llie_last_error", "llie_version", "llie_create", "llie_destroy", "llie_num_params", "llie_param_info",
+    "llie_load_param", "llie_params_loaded", "llie_workspace_bytes", "llie_unet_forward", "llie_module_forward",
+    "llie_lcm_step", "llie_add_noise", "llie_enhance", "llie_algorithmic_bytes", "llie_flops",
+]
+
+
+class LibraryNotBuilt(RuntimeError):
+    pass
+
+
+class Config(C.Structure):
+    _fields_ = [
+        ("kind", C.c_int), ("compute_dtype", C.c_int), ("in_channels", C.c_int), ("out_channels", C.c_int),
+        ("base_channels", C.c_int), ("channel_multipliers", C.c_int * 4), ("num_res_blocks", C.c_int),
+        ("expansion_ratio", C.c_int), ("time_embed_dim", C.c_int), ("num_attention_heads", C.c_int),
+        ("image_size", C.c_int), ("attention_resolutions", C.c_int * 2),
+    ]
+
+
+class StepCoef(C.Structure):
+    _fields_ = [
+        ("sqrt_alpha_t", C.c_float), ("sqrt_beta_t", C.c_float), ("sqrt_alpha_prev", C.c_float),
+        ("sqrt_beta_prev", C.c_float), ("is_last", C.c_int), ("v_prediction", C.c_int),
+    ]
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """Load the engine once.  torch must already be imported by the caller so that the HIP runtime the
+    library binds to (SONAME libamdhip64.so.7) is the one PyTorch-ROCm loaded."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise LibraryNotBuilt(
+            f"{LIB_PATH} not found: run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C cv-diffusion-model_amd/csrc`).  There is no CPU/PyTorch fallback for the hot path.")
+    import torch  # noqa: F401  (loads libamdhip64 first)
+    L = C.CDLL(LIB_PATH)
+    vp, i64, ci = C.c_void_p, C.c_int64, C.c_int
+    L.llie_last_error.restype = C.c_char_p
+    L.llie_version.restype = C.c_char_p
+    L.llie_create.argtypes = [C.POINTER(Config), C.POINTER(vp)]
+    L.llie_destroy.argtypes = [vp]
+    L.llie_destroy.restype = None
+    L.llie_num_params.argtypes = [vp]
+    L.llie_param_info.argtypes = [vp, ci, C.c_char_p, C.c_size_t, C.POINTER(i64), C.POINTER(ci), C.POINTER(i64)]
+    L.llie_load_param.argtypes = [vp, C.c_char_p, vp, i64, vp]
+    L.llie_params_loaded.argtypes = [vp]
+    L.llie_workspace_bytes.argtypes = [vp, ci, ci, ci]
+    L.llie_workspace_bytes.restype = i64
+    L.llie_unet_forward.argtypes = [vp, vp, vp, vp, ci, vp, ci, vp, i64, vp]
+    L.llie_module_forward.argtypes = [vp, vp, vp, vp, ci, ci, ci, vp, i64, vp]
+    L.llie_lcm_step.argtypes = [vp, vp, vp, vp, vp, vp, i64, C.POINTER(StepCoef), vp]
+    L.llie_add_noise.argtypes = [vp, vp, vp, vp, vp, ci, i64, ci, vp]
+    L.llie_enhance.argtypes = [vp, vp, vp, vp, C.POINTER(StepCoef), ci, vp, vp, vp, ci, vp, i64, vp]
+    L.llie_algorithmic_bytes.argtypes = [vp, ci]
+    L.llie_algorithmic_bytes.restype = i64
+    L.llie_flops.argtypes = [vp, ci]
+    L.llie_flops.restype = i64
+    _lib = L
+    return L
+
+
+def last_error() -> str:
+    return lib().llie_last_error().decode()
+
+
+def check(rc: int, what: str = "") -> None:
+    """Map llie_status / hipError_t to the exception types the reference raises."""
+    if rc == 0:
+        return
+    msg = f"{what}: {last_error()}" if what else last_error()
+    if rc in (ERR_CONFIG,):
+        raise ValueError(msg)            # nn.GroupNorm's ValueError (efficient_unet.py:170)
+    if rc in (ERR_KEY, ERR_NOT_LOADED):
+        raise RuntimeError(msg)          # load_state_dict's RuntimeError
+    if rc == ERR_SHAPE or rc == ERR_ARG:
+        raise ValueError(msg or f"invalid argument ({rc})")
+    if rc == ERR_NO_DEVICE:
+        raise RuntimeError(msg or "no HIP device: the LCM hot path runs only on an MI355X-class GPU")
+    raise RuntimeError(msg or f"llie error {rc}")
+
+
+def dtype_code(name) -> int:
+    import torch
+    table = {"fp32": 0, "float32": 0, torch.float32: 0, "fp16": 1, "float16": 1, torch.float16: 1,
+             "bf16": 2, "bfloat16": 2, torch.bfloat16: 2}
+    if name not in table:
+        raise ValueError(f"unsupported compute dtype {name!r}; choose fp32, fp16 or bf16")
+    return table[name]
+
+
+class Handle:
+    """Owns one llie_ctx."""
+
+    def __init__(self, cfg: Config):
+        self._L = lib()
+        h = C.c_void_p()
+        check(self._L.llie_create(C.byref(cfg), C.byref(h)), "llie_create")
+        self.h = h
+        self.cfg = cfg
+
+    def close(self):
+        if getattr(self, "h", None):
+            self._L.llie_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+    def params(self) -> List[Tuple[str, Tuple[int, ...]]]:
+        out = []
+        buf = C.create_string_buffer(256)
+        n, nd, shp = C.c_int64(), C.c_int(), (C.c_int64 * 4)()
+        for i in range(self._L.llie_num_params(self.h)):
+            check(self._L.llie_param_info(self.h, i, buf, 256, C.byref(n), C.byref(nd), shp))
+            out.append((buf.value.decode(), tuple(int(shp[d]) for d in range(nd.value))))
+        return out
+
+    def load_param(self, key: str, tensor, stream: int) -> None:
+        check(self._L.llie_load_param(self.h, key.encode(), tensor.data_ptr(), tensor.numel(), stream), "load_state_dict")
+
+    def params_loaded(self) -> bool:
+        return bool(self._L.llie_params_loaded(self.h))
+
+    def workspace_bytes(self, batch: int, h: int = 0, w: int = 0) -> int:
+        n = self._L.llie_workspace_bytes(self.h, batch, h, w)
+        if n < 0:
+            check(int(n), "llie_workspace_bytes")
+        return int(n)
+
+    def algorithmic_bytes(self, batch: int) -> int:
+        return int(self._L.llie_algorithmic_bytes(self.h, batch))
+
+    def flops(self, batch: int) -> int:
+        return int(self._L.llie_flops(self.h, batch))

@@ -1,0 +1,118 @@
+// Shared device helpers for the gfx950 kernels of libllie_hip.so.
+// Wavefront = 64 everywhere; activations are NHWC with 16-byte channel vectors per lane.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "kernels.h"
+
+namespace llie {
+
+typedef _Float16 half_t;
+typedef __bf16 bf16_t;
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kWave = 64;
+
+// ---------------------------------------------------------------------------------------------
+// Element traits: VEC = elements per 16-byte lane vector.
+template <typename T> struct Elem;
+template <> struct Elem<float> {
+  static constexpr int VEC = 4;
+  typedef f32x4 vec_t;
+};
+template <> struct Elem<half_t> {
+  static constexpr int VEC = 8;
+  typedef f16x8 vec_t;
+};
+template <> struct Elem<bf16_t> {
+  static constexpr int VEC = 8;
+  typedef bf16x8 vec_t;
+};
+
+template <typename T> __device__ __forceinline__ typename Elem<T>::vec_t ld_vec(const T* p) {
+  return *reinterpret_cast<const typename Elem<T>::vec_t*>(p);
+}
+template <typename T> __device__ __forceinline__ void st_vec(T* p, typename Elem<T>::vec_t v) {
+  *reinterpret_cast<typename Elem<T>::vec_t*>(p) = v;
+}
+// 16-byte vector <-> float[VEC]
+template <typename T> __device__ __forceinline__ void vec_to_f32(typename Elem<T>::vec_t v, float* f) {
+#pragma unroll
+  for (int i = 0; i < Elem<T>::VEC; ++i) f[i] = (float)v[i];
+}
+template <typename T> __device__ __forceinline__ typename Elem<T>::vec_t f32_to_vec(const float* f) {
+  typename Elem<T>::vec_t v;
+#pragma unroll
+  for (int i = 0; i < Elem<T>::VEC; ++i) v[i] = (T)f[i];
+  return v;
+}
+template <typename T> __device__ __forceinline__ void ld_f32(const T* p, float* f) { vec_to_f32<T>(ld_vec<T>(p), f); }
+template <typename T> __device__ __forceinline__ void st_f32(T* p, const float* f) { st_vec<T>(p, f32_to_vec<T>(f)); }
+// value as the consumer will see it after storage in T
+template <typename T> __device__ __forceinline__ float round_to(float x) { return (float)(T)x; }
+
+__device__ __forceinline__ float relu6f(float x) { return __builtin_fminf(__builtin_fmaxf(x, 0.f), 6.f); }
+__device__ __forceinline__ float siluf(float x) { return x / (1.f + __expf(-x)); }
+__device__ __forceinline__ float sigmoidf(float x) { return 1.f / (1.f + __expf(-x)); }
+
+__device__ __forceinline__ float apply_act(float x, int act) {
+  if (act == ACT_RELU6) return relu6f(x);
+  if (act == ACT_SILU) return siluf(x);
+  return x;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Wavefront (64-lane) reductions by xor-shuffle.
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// MFMA wrappers.  One k-chunk = 32 K-values; lane half h = lane>>5 owns k in [16h, 16h+16) of the
+// chunk for BOTH operands (any k permutation is legal as long as A and B agree), so each lane reads
+// 16 contiguous elements of its row per chunk.
+template <typename T> struct Mfma;
+template <> struct Mfma<float> {
+  // a, b: 16 floats (this lane's k-slice of its A row / W row)
+  static __device__ __forceinline__ void chunk(const float* a, const float* b, f32x16& acc) {
+#pragma unroll
+    for (int s = 0; s < 16; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b[s], acc, 0, 0, 0);
+  }
+};
+template <> struct Mfma<half_t> {
+  static __device__ __forceinline__ void chunk(const half_t* a, const half_t* b, f32x16& acc) {
+    const f16x8* av = reinterpret_cast<const f16x8*>(a);
+    const f16x8* bv = reinterpret_cast<const f16x8*>(b);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[0], bv[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[1], bv[1], acc, 0, 0, 0);
+  }
+};
+template <> struct Mfma<bf16_t> {
+  static __device__ __forceinline__ void chunk(const bf16_t* a, const bf16_t* b, f32x16& acc) {
+    const bf16x8* av = reinterpret_cast<const bf16x8*>(a);
+    const bf16x8* bv = reinterpret_cast<const bf16x8*>(b);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[0], bv[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[1], bv[1], acc, 0, 0, 0);
+  }
+};
+// C/D layout of every 32x32 MFMA (dtype independent): col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+__device__ __forceinline__ int mfma_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+
+// LDS row pitch (in elements) for a [rows][32] T tile: 32 elements + one 16-byte pad => conflict-free
+// ds_read_b128 of 16-lane groups (80-byte rows for 2-byte T, 144-byte rows for float).
+template <typename T> struct TilePitch { static constexpr int value = 32 + Elem<T>::VEC; };
+
+}  // namespace llie

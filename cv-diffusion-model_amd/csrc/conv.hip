@@ -1,0 +1,415 @@
+// Dense 3x3 convolutions of the denoiser (gfx950).
+//   init_conv   (efficient_unet.py:420,553)  Cin=6 -> C0, reads the two fp32 NCHW halves of
+//               torch.cat([latents, low_light], 1) (low_light_diffusion.py:222) directly: the concat is virtual.
+//   final head  (efficient_unet.py:528-530,600-602)  GroupNorm affine + SiLU fused into the tile load,
+//               C0 -> 3, writes the fp32 NCHW noise prediction.
+//   Downsample  (efficient_unet.py:367)  3x3 stride 2       } implicit GEMM on MFMA: M = 8 x TW output pixels,
+//   Upsample    (efficient_unet.py:383-384) bilinear x2 + 3x3 } N = Cout tile, K = 9 taps x Cin; the upsampled
+//               halo patch is interpolated on the fly into LDS, so the 4x tensor never reaches HBM.
+#include "common.h"
+#include "kernels.h"
+
+namespace llie {
+
+// =============================================================================================
+// init_conv: one thread = one output pixel x 32 output channels (K = 54 is too small for MFMA tiles
+// to pay; weights are wave-uniform and come through the scalar cache).
+// Weight layout here: [k = ci*9 + tap][Cout] fp32 (repacked at load).
+template <typename T>
+__global__ void __launch_bounds__(256) init_conv_kernel(const InitConvArgs a) {
+  constexpr int VEC = Elem<T>::VEC;
+  constexpr int MAXC = 8;
+  __shared__ float patch[MAXC][18][19];
+  __shared__ float red[4][2][32];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tiles_x = a.W / 16;
+  const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x, b = blockIdx.y;
+  const int x0 = tx * 16, y0 = ty * 16;
+  const int Cin = a.c0 + a.c1;
+  const size_t plane = (size_t)a.H * a.W;
+  for (int i = tid; i < Cin * 18 * 18; i += 256) {
+    const int ci = i / 324, r = i % 324;
+    const int py = r / 18, px = r % 18;
+    const int gy = y0 + py - 1, gx = x0 + px - 1;
+    float v = 0.f;
+    if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {
+      const float* src = ci < a.c0 ? a.x0 + ((size_t)b * a.c0 + ci) * plane : a.x1 + ((size_t)b * a.c1 + (ci - a.c0)) * plane;
+      v = src[(size_t)gy * a.W + gx];
+    }
+    patch[ci][py][px] = v;
+  }
+  __syncthreads();
+  const int py = tid >> 4, px = tid & 15;
+  const float* __restrict__ w = a.w;
+  T* out = reinterpret_cast<T*>(a.out) + (((size_t)b * a.H + y0 + py) * a.W + x0 + px) * a.Cout;
+  const int ntiles = tiles_x * (a.H / 16);
+  for (int oc0 = 0; oc0 < a.Cout; oc0 += 32) {
+    float acc[32];
+#pragma unroll
+    for (int o = 0; o < 32; ++o) acc[o] = a.bias[oc0 + o];
+    for (int ci = 0; ci < Cin; ++ci) {
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const float v = patch[ci][py + tap / 3][px + tap % 3];
+        const float* wr = w + (size_t)(ci * 9 + tap) * a.Cout + oc0;
+#pragma unroll
+        for (int o = 0; o < 32; ++o) acc[o] += wr[o] * v;
+      }
+    }
+    float q[32];
+#pragma unroll
+    for (int o = 0; o < 32; o += VEC) {
+      typename Elem<T>::vec_t ov = f32_to_vec<T>(acc + o);
+      st_vec<T>(out + oc0 + o, ov);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) q[o + e] = (float)ov[e];
+    }
+    if (a.stats) {
+#pragma unroll
+      for (int o = 0; o < 32; ++o) {
+        const float s1 = wave_sum(q[o]), s2 = wave_sum(q[o] * q[o]);
+        if (lane == 0) {
+          red[wave][0][o] = s1;
+          red[wave][1][o] = s2;
+        }
+      }
+      __syncthreads();
+      if (tid < 64) {
+        const int which = tid >> 5, o = tid & 31;
+        const float t = red[0][which][o] + red[1][which][o] + red[2][which][o] + red[3][which][o];
+        a.stats[((size_t)(b * ntiles + blockIdx.x) * 2 + which) * a.Cout + oc0 + o] = t;
+      }
+      __syncthreads();
+    }
+  }
+}
+int init_conv_ntiles(int H, int W) { return (H / 16) * (W / 16); }
+hipError_t launch_init_conv(int dtype, const InitConvArgs& a, hipStream_t s) {
+  if (a.H % 16 || a.W % 16 || a.Cout % 32 || a.c0 + a.c1 > 8) return hipErrorInvalidValue;
+  dim3 grid((a.H / 16) * (a.W / 16), a.B);
+  switch (dtype) {
+    case 0: hipLaunchKernelGGL(init_conv_kernel<float>, grid, dim3(256), 0, s, a); break;
+    case 1: hipLaunchKernelGGL(init_conv_kernel<half_t>, grid, dim3(256), 0, s, a); break;
+    case 2: hipLaunchKernelGGL(init_conv_kernel<bf16_t>, grid, dim3(256), 0, s, a); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+// =============================================================================================
+// final head: affine (GroupNorm) + SiLU applied once per element while staging a 18x18 halo tile of
+// 32 channels into LDS (channel-major, so a wave's pixel-consecutive reads are conflict free), then
+// one thread = one pixel x Cout(<=4) outputs.  Weight layout: [tap][C][4] fp32, zero padded (repacked at load).
+template <typename T>
+__global__ void __launch_bounds__(256) final_conv_kernel(const FinalConvArgs a) {
+  constexpr int VEC = Elem<T>::VEC;
+  constexpr int VPP = 32 / VEC;  // vectors per pixel per 32-channel chunk
+  __shared__ float patch[32][18][19];
+  const int tid = threadIdx.x;
+  const int tiles_x = a.W / 16;
+  const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x, b = blockIdx.y;
+  const int x0 = tx * 16, y0 = ty * 16;
+  const int py = tid >> 4, px = tid & 15;
+  const T* in = reinterpret_cast<const T*>(a.in) + (size_t)b * a.H * a.W * a.C;
+  const float* __restrict__ w = a.w;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int cc = 0; cc < a.C; cc += 32) {
+    if (cc) __syncthreads();
+    for (int i = tid; i < 18 * 18 * VPP; i += 256) {
+      const int pix = i / VPP, cv = (i % VPP) * VEC;
+      const int ppy = pix / 18, ppx = pix % 18;
+      const int gy = y0 + ppy - 1, gx = x0 + ppx - 1;
+      float f[VEC];
+      if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {
+        ld_f32<T>(in + ((size_t)gy * a.W + gx) * a.C + cc + cv, f);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          const int c = cc + cv + e;
+          f[e] = siluf(f[e] * a.as[(size_t)b * a.C + c] + a.ab[(size_t)b * a.C + c]);
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) f[e] = 0.f;
+      }
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) patch[cv + e][ppy][ppx] = f[e];
+    }
+    __syncthreads();
+    for (int ci = 0; ci < 32; ++ci) {
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const float v = patch[ci][py + tap / 3][px + tap % 3];
+        const float* wr = w + ((size_t)tap * a.C + cc + ci) * 4;
+#pragma unroll
+        for (int o = 0; o < 4; ++o) acc[o] += wr[o] * v;
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 0; o < 4; ++o)
+    if (o < a.Cout) a.out[(((size_t)b * a.Cout + o) * a.H + y0 + py) * a.W + x0 + px] = acc[o] + a.bias[o];
+}
+hipError_t launch_final_conv(int dtype, const FinalConvArgs& a, hipStream_t s) {
+  if (a.H % 16 || a.W % 16 || a.C % 32 || a.Cout > 4) return hipErrorInvalidValue;
+  dim3 grid((a.H / 16) * (a.W / 16), a.B);
+  switch (dtype) {
+    case 0: hipLaunchKernelGGL(final_conv_kernel<float>, grid, dim3(256), 0, s, a); break;
+    case 1: hipLaunchKernelGGL(final_conv_kernel<half_t>, grid, dim3(256), 0, s, a); break;
+    case 2: hipLaunchKernelGGL(final_conv_kernel<bf16_t>, grid, dim3(256), 0, s, a); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+// =============================================================================================
+// Implicit-GEMM 3x3 conv on MFMA.  MODE 0: stride 2, pad 1.  MODE 1: bilinear x2 (align_corners=False:
+// src = (dst+0.5)/2 - 0.5 clamped at 0, upper neighbour clamped at n-1) then stride 1, pad 1.
+template <typename T, int MODE, int TW, int BN, int WM, int WN>
+__global__ void __launch_bounds__(WM* WN * 64) conv3x3_kernel(const Conv3Args a) {
+  constexpr int NT = WM * WN * 64;
+  constexpr int TH = 8, BM = TH * TW;
+  constexpr int VEC = Elem<T>::VEC, VPR = 32 / VEC, PITCH = TilePitch<T>::value;
+  constexpr int MI = BM / (WM * 32), NI = BN / (WN * 32);
+  constexpr int PH = MODE == 0 ? 2 * TH + 1 : TH + 2;
+  constexpr int PW = MODE == 0 ? 2 * TW + 1 : TW + 2;
+  constexpr int B_VECS = BN * VPR, B_PER = (B_VECS + NT - 1) / NT;
+  constexpr int CP = BN + 4;
+  typedef typename Elem<T>::vec_t vec_t;
+  static_assert(NT % VPR == 0, "mapping");
+
+  extern __shared__ __align__(16) unsigned char smem[];
+  T* sP = reinterpret_cast<T*>(smem);
+  T* sB = sP + PH * PW * PITCH;
+  float* sC = reinterpret_cast<float*>(smem);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int Ho = MODE == 0 ? a.Hi / 2 : a.Hi * 2, Wo = MODE == 0 ? a.Wi / 2 : a.Wi * 2;
+  const int nb = a.Cout / BN, tiles_x = Wo / TW, tiles = tiles_x * (Ho / TH);
+  int bid = blockIdx.x;
+  const int ntile = bid % nb; bid /= nb;
+  const int tile = bid % tiles, b = bid / tiles;
+  const int oy0 = (tile / tiles_x) * TH, ox0 = (tile % tiles_x) * TW;
+  const int n0 = ntile * BN;
+  const int kv = (tid % VPR) * VEC;
+  const T* in = reinterpret_cast<const T*>(a.in) + (size_t)b * a.Hi * a.Wi * a.Cin;
+  const T* wbase = reinterpret_cast<const T*>(a.w);
+
+  f32x16 acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // per-lane patch offsets of this lane's A rows (tap (0,0)); tap (dy,dx) adds (dy*PW+dx)*PITCH
+  int arow[MI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+    const int m = (wm * MI + i) * 32 + (lane & 31);
+    const int py = m / TW, px = m % TW;
+    arow[i] = (MODE == 0 ? (2 * py * PW + 2 * px) : (py * PW + px)) * PITCH + (lane >> 5) * 16;
+  }
+
+  vec_t rb[B_PER];
+  auto prefetch_w = [&](int tap, int c0) {
+#pragma unroll
+    for (int i = 0; i < B_PER; ++i) {
+      const int idx = tid + i * NT;
+      if (B_VECS % NT == 0 || idx < B_VECS) {
+        const int n = idx / VPR;
+        rb[i] = ld_vec<T>(wbase + ((size_t)tap * a.Cout + n0 + n) * a.Cin + c0 + kv);
+      }
+    }
+  };
+  auto stage_w = [&]() {
+#pragma unroll
+    for (int i = 0; i < B_PER; ++i) {
+      const int idx = tid + i * NT;
+      if (B_VECS % NT == 0 || idx < B_VECS) st_vec<T>(sB + (idx / VPR) * PITCH + kv, rb[i]);
+    }
+  };
+
+  for (int c0 = 0; c0 < a.Cin; c0 += 32) {
+    prefetch_w(0, c0);
+    // ---- stage the input patch for this channel chunk
+    for (int i = tid; i < PH * PW * VPR; i += NT) {
+      const int pix = i / VPR;
+      const int ppy = pix / PW, ppx = pix % PW;
+      vec_t v;
+      if (MODE == 0) {
+        const int gy = 2 * oy0 - 1 + ppy, gx = 2 * ox0 - 1 + ppx;
+        if (gy >= 0 && gy < a.Hi && gx >= 0 && gx < a.Wi) {
+          v = ld_vec<T>(in + ((size_t)gy * a.Wi + gx) * a.Cin + c0 + kv);
+        } else {
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) v[e] = (T)0.f;
+        }
+      } else {
+        const int uy = oy0 - 1 + ppy, ux = ox0 - 1 + ppx;  // coordinates in the upsampled image
+        if (uy >= 0 && uy < Ho && ux >= 0 && ux < Wo) {
+          float sy = ((float)uy + 0.5f) * 0.5f - 0.5f, sx = ((float)ux + 0.5f) * 0.5f - 0.5f;
+          sy = sy < 0.f ? 0.f : sy;
+          sx = sx < 0.f ? 0.f : sx;
+          const int iy0 = (int)sy, ix0 = (int)sx;
+          const int iy1 = min(iy0 + 1, a.Hi - 1), ix1 = min(ix0 + 1, a.Wi - 1);
+          const float ly1 = sy - (float)iy0, lx1 = sx - (float)ix0;
+          const float ly0 = 1.f - ly1, lx0 = 1.f - lx1;
+          float f00[VEC], f01[VEC], f10[VEC], f11[VEC], f[VEC];
+          ld_f32<T>(in + ((size_t)iy0 * a.Wi + ix0) * a.Cin + c0 + kv, f00);
+          ld_f32<T>(in + ((size_t)iy0 * a.Wi + ix1) * a.Cin + c0 + kv, f01);
+          ld_f32<T>(in + ((size_t)iy1 * a.Wi + ix0) * a.Cin + c0 + kv, f10);
+          ld_f32<T>(in + ((size_t)iy1 * a.Wi + ix1) * a.Cin + c0 + kv, f11);
+#pragma unroll
+          for (int e = 0; e < VEC; ++e)
+            f[e] = ly0 * (lx0 * f00[e] + lx1 * f01[e]) + ly1 * (lx0 * f10[e] + lx1 * f11[e]);
+          v = f32_to_vec<T>(f);
+        } else {
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) v[e] = (T)0.f;
+        }
+      }
+      st_vec<T>(sP + pix * PITCH + kv, v);
+    }
+    for (int tap = 0; tap < 9; ++tap) {
+      stage_w();
+      __syncthreads();  // patch (first tap) and W tile visible
+      if (tap + 1 < 9) prefetch_w(tap + 1, c0);
+      const int toff = ((tap / 3) * PW + (tap % 3)) * PITCH;
+      T fa[MI][16], fb[NI][16];
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        const T* p = sP + arow[i] + toff;
+#pragma unroll
+        for (int q = 0; q < 16 / VEC; ++q) *reinterpret_cast<vec_t*>(&fa[i][q * VEC]) = *reinterpret_cast<const vec_t*>(p + q * VEC);
+      }
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        const T* p = sB + ((wn * NI + j) * 32 + (lane & 31)) * PITCH + (lane >> 5) * 16;
+#pragma unroll
+        for (int q = 0; q < 16 / VEC; ++q) *reinterpret_cast<vec_t*>(&fb[j][q * VEC]) = *reinterpret_cast<const vec_t*>(p + q * VEC);
+      }
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) Mfma<T>::chunk(fa[i], fb[j], acc[i][j]);
+      __syncthreads();  // everyone done with sB (and, after tap 8, with the patch)
+    }
+  }
+
+  // ---- epilogue (same scheme as the pointwise GEMM)
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (wm * MI + i) * 32 + mfma_row(r, lane);
+        const int col = (wn * NI + j) * 32 + (lane & 31);
+        sC[row * CP + col] = acc[i][j][r];
+      }
+  __syncthreads();
+  constexpr int VR = BN / VEC, RPP = NT / VR;
+  static_assert(NT % VR == 0 && VR <= 64, "epilogue mapping");
+  const int cv = tid % VR, r0 = tid / VR;
+  float bias[VEC], s1[VEC], s2[VEC];
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) {
+    bias[e] = a.bias ? a.bias[n0 + cv * VEC + e] : 0.f;
+    s1[e] = 0.f;
+    s2[e] = 0.f;
+  }
+  T* outp = reinterpret_cast<T*>(a.out) + (size_t)b * Ho * Wo * a.Cout;
+  for (int row = r0; row < BM; row += RPP) {
+    float v[VEC];
+    const float* pc = sC + row * CP + cv * VEC;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) v[e] = pc[e] + bias[e];
+    const int oy = oy0 + row / TW, ox = ox0 + row % TW;
+    vec_t ov = f32_to_vec<T>(v);
+    st_vec<T>(outp + ((size_t)oy * Wo + ox) * a.Cout + n0 + cv * VEC, ov);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      const float q = (float)ov[e];
+      s1[e] += q;
+      s2[e] += q * q;
+    }
+  }
+  if (a.stats) {
+#pragma unroll
+    for (int o = VR; o < 64; o <<= 1)
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        s1[e] += __shfl_xor(s1[e], o, 64);
+        s2[e] += __shfl_xor(s2[e], o, 64);
+      }
+    float* red = sC + BM * CP;
+    constexpr int NW = NT / 64;
+    if (lane < VR) {
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        red[(wave * 2 + 0) * BN + cv * VEC + e] = s1[e];
+        red[(wave * 2 + 1) * BN + cv * VEC + e] = s2[e];
+      }
+    }
+    __syncthreads();
+    for (int i = tid; i < 2 * BN; i += NT) {
+      const int which = i / BN, c = i % BN;
+      float t = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) t += red[(w * 2 + which) * BN + c];
+      a.stats[((size_t)(b * tiles + tile) * 2 + which) * a.Cout + n0 + c] = t;
+    }
+  }
+}
+
+static int conv_tw(int Wo) { return (Wo % 16 == 0) ? 16 : 8; }
+int conv3x3_ntiles(int Ho, int Wo) { return (Ho / 8) * (Wo / conv_tw(Wo)); }
+
+template <typename T, int MODE, int TW, int BN, int WM, int WN>
+static hipError_t launch_conv_cfg(const Conv3Args& a, hipStream_t s) {
+  constexpr int NT = WM * WN * 64, BM = 8 * TW, PITCH = TilePitch<T>::value;
+  constexpr int PH = MODE == 0 ? 17 : 10, PW = MODE == 0 ? 2 * TW + 1 : TW + 2;
+  constexpr size_t tiles = (size_t)(PH * PW + BN) * PITCH * sizeof(T);
+  constexpr size_t ctile = (size_t)BM * (BN + 4) * 4 + (size_t)(NT / 64) * 2 * BN * 4;
+  constexpr size_t lds = tiles > ctile ? tiles : ctile;
+  static bool attr_done = false;
+  if (!attr_done && lds > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_kernel<T, MODE, TW, BN, WM, WN>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    attr_done = true;
+  }
+  const int Ho = MODE == 0 ? a.Hi / 2 : a.Hi * 2, Wo = MODE == 0 ? a.Wi / 2 : a.Wi * 2;
+  const unsigned grid = (unsigned)(a.B * (Ho / 8) * (Wo / TW) * (a.Cout / BN));
+  hipLaunchKernelGGL((conv3x3_kernel<T, MODE, TW, BN, WM, WN>), dim3(grid), dim3(NT), lds, s, a);
+  return hipGetLastError();
+}
+
+template <typename T, int MODE>
+static hipError_t launch_conv_t(const Conv3Args& a, hipStream_t s) {
+  const int Ho = MODE == 0 ? a.Hi / 2 : a.Hi * 2, Wo = MODE == 0 ? a.Wi / 2 : a.Wi * 2;
+  if (Ho % 8 || Wo % 8 || a.Cin % 32 || a.Cout % 32 || (MODE == 0 && (a.Hi % 2 || a.Wi % 2))) return hipErrorInvalidValue;
+  const int BN = (a.Cout % 128 == 0) ? 128 : ((a.Cout % 64 == 0) ? 64 : 32);
+  if (conv_tw(Wo) == 16) {
+    if (BN == 128) return launch_conv_cfg<T, MODE, 16, 128, 2, 2>(a, s);
+    if (BN == 64) return launch_conv_cfg<T, MODE, 16, 64, 2, 2>(a, s);
+    return launch_conv_cfg<T, MODE, 16, 32, 4, 1>(a, s);
+  }
+  if (BN == 128) return launch_conv_cfg<T, MODE, 8, 128, 2, 2>(a, s);
+  if (BN == 64) return launch_conv_cfg<T, MODE, 8, 64, 2, 2>(a, s);
+  return launch_conv_cfg<T, MODE, 8, 32, 2, 1>(a, s);
+}
+
+hipError_t launch_conv3x3(int dtype, const Conv3Args& a, hipStream_t s) {
+  if (a.mode != 0 && a.mode != 1) return hipErrorInvalidValue;
+  switch (dtype) {
+    case 0: return a.mode == 0 ? launch_conv_t<float, 0>(a, s) : launch_conv_t<float, 1>(a, s);
+    case 1: return a.mode == 0 ? launch_conv_t<half_t, 0>(a, s) : launch_conv_t<half_t, 1>(a, s);
+    case 2: return a.mode == 0 ? launch_conv_t<bf16_t, 0>(a, s) : launch_conv_t<bf16_t, 1>(a, s);
+  }
+  return hipErrorInvalidValue;
+}
+
+}  // namespace llie

@@ -1,0 +1,286 @@
+// Pointwise (1x1 conv) GEMM on MFMA for gfx950.
+//
+// Replaces the reference's 1x1 nn.Conv2d call sites (expand / project / skip efficient_unet.py:174,186,199;
+// to_qkv / to_out :265-267) together with the elementwise work eager PyTorch runs around them:
+//   prologue (on the A tile, while staging to LDS):  GroupNorm affine [+ReLU6]  (norm1 :207-208) or the
+//                                                    SE gate multiply (:100) -- a per-(image, channel) FMA;
+//   K-concatenation of up to three A segments:       virtual torch.cat([h, skip]) (:588) and the
+//                                                    project+skip pair sharing one accumulator (:226,231);
+//   epilogue:                                        bias, identity residual (:234), per-channel
+//                                                    (sum, sumsq) slab for the next GroupNorm.
+// A rows are NHWC pixels (K contiguous), W is [N][K] (K contiguous): both MFMA operands read 16
+// contiguous K-elements per lane.  fp32 accumulation always; T = float uses the exact-f32 MFMA.
+#include "common.h"
+#include "kernels.h"
+
+namespace llie {
+
+template <typename T, int BM, int BN, int WM, int WN>
+__global__ void __launch_bounds__(WM* WN * 64) pw_gemm_kernel(const GemmArgs g) {
+  constexpr int NT = WM * WN * 64;
+  constexpr int VEC = Elem<T>::VEC;
+  constexpr int VPR = 32 / VEC;  // 16-byte vectors per 32-wide k-chunk row
+  constexpr int PITCH = TilePitch<T>::value;
+  constexpr int MI = BM / (WM * 32), NI = BN / (WN * 32);
+  constexpr int A_VECS = BM * VPR, B_VECS = BN * VPR;
+  constexpr int A_PER = (A_VECS + NT - 1) / NT, B_PER = (B_VECS + NT - 1) / NT;
+  constexpr int CP = BN + 4;  // fp32 C-tile pitch
+  typedef typename Elem<T>::vec_t vec_t;
+  static_assert(NT % VPR == 0, "thread->k-vector mapping must be loop invariant");
+
+  extern __shared__ __align__(16) unsigned char smem[];
+  T* sA = reinterpret_cast<T*>(smem);
+  T* sB = sA + BM * PITCH;
+  float* sC = reinterpret_cast<float*>(smem);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int nb = g.N / BN;
+  const int mt = blockIdx.x / nb, ntile = blockIdx.x % nb;  // n fastest: neighbours share the A tile in L2
+  const int m0 = mt * BM, n0 = ntile * BN;
+  const int img = m0 / g.P;
+  const int kv = (tid % VPR) * VEC;  // this thread's k offset inside every chunk
+
+  f32x16 acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  vec_t ra[A_PER], rb[B_PER];
+  float rs[VEC], rbv[VEC];
+  int r_aff = 0, r_act = 0;
+
+  const int koff1 = g.seg[0].ch, koff2 = g.seg[0].ch + g.seg[1].ch;
+  const T* wbase = reinterpret_cast<const T*>(g.w);
+
+  auto prefetch = [&](int k0) {
+    const int s = (g.nseg > 1 && k0 >= koff1) + (g.nseg > 2 && k0 >= koff2);
+    const GemmSeg sg = g.seg[s];
+    const int cl = k0 - (s == 0 ? 0 : (s == 1 ? koff1 : koff2));
+    const T* abase = reinterpret_cast<const T*>(sg.ptr);
+#pragma unroll
+    for (int i = 0; i < A_PER; ++i) {
+      const int idx = tid + i * NT;
+      if (A_VECS % NT == 0 || idx < A_VECS) {
+        const int row = idx / VPR;
+        ra[i] = ld_vec<T>(abase + (size_t)(m0 + row) * sg.ch + cl + kv);
+      }
+    }
+    r_aff = sg.as != nullptr;
+    r_act = sg.act;
+    if (r_aff) {
+      const float* ps = sg.as + (size_t)img * sg.aff_ld + cl + kv;
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) rs[e] = ps[e];
+      if (sg.ab) {
+        const float* pb = sg.ab + (size_t)img * sg.aff_ld + cl + kv;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) rbv[e] = pb[e];
+      } else {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) rbv[e] = 0.f;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < B_PER; ++i) {
+      const int idx = tid + i * NT;
+      if (B_VECS % NT == 0 || idx < B_VECS) {
+        const int n = idx / VPR;
+        rb[i] = ld_vec<T>(wbase + (size_t)(n0 + n) * g.K + k0 + kv);
+      }
+    }
+  };
+
+  auto stage = [&]() {
+#pragma unroll
+    for (int i = 0; i < A_PER; ++i) {
+      const int idx = tid + i * NT;
+      if (A_VECS % NT == 0 || idx < A_VECS) {
+        const int row = idx / VPR;
+        vec_t v = ra[i];
+        if (r_aff) {
+          float f[VEC];
+          vec_to_f32<T>(v, f);
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) {
+            float x = f[e] * rs[e] + rbv[e];
+            f[e] = r_act == ACT_RELU6 ? relu6f(x) : x;
+          }
+          v = f32_to_vec<T>(f);
+        }
+        st_vec<T>(sA + row * PITCH + kv, v);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < B_PER; ++i) {
+      const int idx = tid + i * NT;
+      if (B_VECS % NT == 0 || idx < B_VECS) {
+        const int n = idx / VPR;
+        st_vec<T>(sB + n * PITCH + kv, rb[i]);
+      }
+    }
+  };
+
+  const int nchunks = g.K / 32;
+  prefetch(0);
+  for (int c = 0; c < nchunks; ++c) {
+    stage();
+    __syncthreads();
+    if (c + 1 < nchunks) prefetch((c + 1) * 32);
+    T fa[MI][16], fb[NI][16];
+    const int lr = lane & 31, lk = (lane >> 5) * 16;
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      const T* p = sA + ((wm * MI + i) * 32 + lr) * PITCH + lk;
+#pragma unroll
+      for (int q = 0; q < 16 / VEC; ++q) *reinterpret_cast<vec_t*>(&fa[i][q * VEC]) = *reinterpret_cast<const vec_t*>(p + q * VEC);
+    }
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const T* p = sB + ((wn * NI + j) * 32 + lr) * PITCH + lk;
+#pragma unroll
+      for (int q = 0; q < 16 / VEC; ++q) *reinterpret_cast<vec_t*>(&fb[j][q * VEC]) = *reinterpret_cast<const vec_t*>(p + q * VEC);
+    }
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NI; ++j) Mfma<T>::chunk(fa[i], fb[j], acc[i][j]);
+    __syncthreads();
+  }
+
+  // ---- epilogue: accumulators -> LDS (fp32) -> 16-byte row vectors (+bias, +residual, stats) -> HBM
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (wm * MI + i) * 32 + mfma_row(r, lane);
+        const int col = (wn * NI + j) * 32 + (lane & 31);
+        sC[row * CP + col] = acc[i][j][r];
+      }
+  __syncthreads();
+
+  constexpr int VR = BN / VEC;   // vectors per output row
+  constexpr int RPP = NT / VR;   // rows per pass
+  static_assert(NT % VR == 0 && VR <= 64, "epilogue mapping");
+  const int cv = tid % VR, r0 = tid / VR;
+  float bias[VEC], s1[VEC], s2[VEC];
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) {
+    bias[e] = g.bias ? g.bias[n0 + cv * VEC + e] : 0.f;
+    s1[e] = 0.f;
+    s2[e] = 0.f;
+  }
+  T* outp = reinterpret_cast<T*>(g.out);
+  const T* resp = reinterpret_cast<const T*>(g.res);
+  for (int row = r0; row < BM; row += RPP) {
+    float v[VEC];
+    const float* pc = sC + row * CP + cv * VEC;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) v[e] = pc[e] + bias[e];
+    const size_t o = (size_t)(m0 + row) * g.N + n0 + cv * VEC;
+    if (resp) {
+      float rr[VEC];
+      ld_f32<T>(resp + o, rr);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) v[e] += rr[e];
+    }
+    vec_t ov = f32_to_vec<T>(v);
+    st_vec<T>(outp + o, ov);
+    if (g.stats) {
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        const float q = (float)ov[e];
+        s1[e] += q;
+        s2[e] += q * q;
+      }
+    }
+  }
+  if (g.stats) {
+    // lanes with equal cv differ in lane bits >= log2(VR)
+#pragma unroll
+    for (int o = VR; o < 64; o <<= 1)
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        s1[e] += __shfl_xor(s1[e], o, 64);
+        s2[e] += __shfl_xor(s2[e], o, 64);
+      }
+    float* red = sC + BM * CP;  // [waves][2][BN]
+    constexpr int NW = NT / 64;
+    if (lane < VR) {
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        red[(wave * 2 + 0) * BN + cv * VEC + e] = s1[e];
+        red[(wave * 2 + 1) * BN + cv * VEC + e] = s2[e];
+      }
+    }
+    __syncthreads();
+    const int ntiles = g.P / BM, tile = (m0 % g.P) / BM;
+    for (int i = tid; i < 2 * BN; i += NT) {
+      const int which = i / BN, c = i % BN;
+      float t = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) t += red[(w * 2 + which) * BN + c];
+      g.stats[((size_t)(img * ntiles + tile) * 2 + which) * g.N + n0 + c] = t;
+    }
+  }
+}
+
+template <typename T, int BM, int BN, int WM, int WN>
+static hipError_t launch_cfg(const GemmArgs& a, hipStream_t s) {
+  constexpr int NT = WM * WN * 64;
+  constexpr int PITCH = TilePitch<T>::value;
+  constexpr size_t tiles = (size_t)(BM + BN) * PITCH * sizeof(T);
+  constexpr size_t ctile = (size_t)BM * (BN + 4) * 4 + (size_t)(NT / 64) * 2 * BN * 4;
+  constexpr size_t lds = tiles > ctile ? tiles : ctile;
+  static bool attr_done = false;
+  if (!attr_done && lds > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pw_gemm_kernel<T, BM, BN, WM, WN>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    attr_done = true;
+  }
+  const unsigned grid = (unsigned)((a.M / BM) * (a.N / BN));
+  hipLaunchKernelGGL((pw_gemm_kernel<T, BM, BN, WM, WN>), dim3(grid), dim3(NT), lds, s, a);
+  return hipGetLastError();
+}
+
+int pw_gemm_tile_rows(int P) { return (P % 128 == 0) ? 128 : 64; }
+
+template <typename T>
+static hipError_t launch_t(const GemmArgs& a, hipStream_t s) {
+  const int BM = pw_gemm_tile_rows(a.P);
+  const int BN = (a.N % 128 == 0) ? 128 : ((a.N % 64 == 0) ? 64 : 32);
+  if (BM == 128) {
+    if (BN == 128) return launch_cfg<T, 128, 128, 2, 2>(a, s);
+    if (BN == 64) return launch_cfg<T, 128, 64, 2, 2>(a, s);
+    return launch_cfg<T, 128, 32, 4, 1>(a, s);
+  }
+  if (BN == 128) return launch_cfg<T, 64, 128, 2, 2>(a, s);
+  if (BN == 64) return launch_cfg<T, 64, 64, 2, 2>(a, s);
+  return launch_cfg<T, 64, 32, 2, 1>(a, s);
+}
+
+hipError_t launch_pw_gemm(int dtype, const GemmArgs& a, hipStream_t s) {
+  // host-side shape contract of the kernel (checked before any launch: an out-of-contract shape
+  // would index out of bounds on the device)
+  if (a.nseg < 1 || a.nseg > 3 || a.N % 32 || a.K % 32 || a.P % 64 || a.M % a.P) return hipErrorInvalidValue;
+  int k = 0;
+  for (int i = 0; i < a.nseg; ++i) {
+    if (a.seg[i].ch % 32 || a.seg[i].ch <= 0 || !a.seg[i].ptr) return hipErrorInvalidValue;
+    k += a.seg[i].ch;
+  }
+  if (k != a.K) return hipErrorInvalidValue;
+  switch (dtype) {
+    case 0: return launch_t<float>(a, s);
+    case 1: return launch_t<half_t>(a, s);
+    case 2: return launch_t<bf16_t>(a, s);
+  }
+  return hipErrorInvalidValue;
+}
+
+}  // namespace llie

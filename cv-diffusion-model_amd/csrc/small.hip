@@ -1,0 +1,604 @@
+// Small / elementwise kernels of the LCM hot path (gfx950): GroupNorm statistics finalisation, SE MLP,
+// time embedding + FiLM projections, linear-attention core, layout conversion, weight repack and the
+// LCM scheduler's elementwise step.  All reductions use fixed orders (bitwise reproducible).
+#include "common.h"
+#include "kernels.h"
+
+namespace llie {
+
+// =============================================================================================
+// GroupNorm finalize: slabs of per-channel (sum, sumsq) -> per-(image, channel) affine.
+// nn.GroupNorm(min(32,C), C) call sites: efficient_unet.py:170-171,263,268,528 (biased variance,
+// eps 1e-5); FiLM fold: efficient_unet.py:215-217  h*(1+scale)+shift after norm2's own affine.
+// One wave per (image, group); tile partials are fp32, the cross-tile combination is fp64.
+__global__ void __launch_bounds__(64) gn_finalize_kernel(const GnFinalizeArgs a) {
+  const int g = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+  const int cg = a.C / a.groups;
+  const int c_lo = g * cg;
+  double s1 = 0.0, s2 = 0.0;
+  int coff = 0;
+  for (int s = 0; s < 2; ++s) {
+    const StatSrc src = a.src[s];
+    if (!src.slab) continue;
+    // channels of this group that live in this source: [lo, hi) in source-local numbering
+    const int lo = max(c_lo - coff, 0), hi = min(c_lo + cg - coff, src.ch);
+    if (hi > lo) {
+      const int w = hi - lo, total = w * src.ntiles;
+      const float* base = src.slab + (size_t)b * src.ntiles * 2 * src.ch;
+      for (int i = lane; i < total; i += 64) {
+        const int t = i / w, c = lo + i % w;
+        s1 += (double)base[(size_t)(t * 2 + 0) * src.ch + c];
+        s2 += (double)base[(size_t)(t * 2 + 1) * src.ch + c];
+      }
+    }
+    coff += src.ch;
+  }
+  s1 = wave_sum(s1);
+  s2 = wave_sum(s2);
+  const double n = (double)cg * (double)a.P;
+  const double mean = s1 / n;
+  double var = s2 / n - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const float rstd = (float)(1.0 / sqrt(var + (double)a.eps));
+  const float fmean = (float)mean;
+  for (int i = lane; i < cg; i += 64) {
+    const int c = c_lo + i;
+    const float ga = a.gamma[c] * rstd;
+    float sc = ga, sh = a.beta[c] - fmean * ga;
+    if (a.film) {
+      const float* f = a.film + (size_t)b * a.film_stride;
+      const float fs = 1.f + f[c], fh = f[a.C + c];
+      sc *= fs;
+      sh = sh * fs + fh;
+    }
+    a.as[(size_t)b * a.C + c] = sc;
+    a.ab[(size_t)b * a.C + c] = sh;
+  }
+}
+
+hipError_t launch_gn_finalize(const GnFinalizeArgs& a, hipStream_t s) {
+  if (a.C % a.groups || a.groups <= 0) return hipErrorInvalidValue;
+  int c = 0;
+  for (int i = 0; i < 2; ++i)
+    if (a.src[i].slab) c += a.src[i].ch;
+  if (c != a.C) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(a.groups, a.B), dim3(64), 0, s, a);
+  return hipGetLastError();
+}
+
+// =============================================================================================
+// Squeeze-and-Excitation MLP (efficient_unet.py:96-100); fc1/fc2 are 1x1 convs on a 1x1 map,
+// i.e. two skinny GEMMs over the batch.  One wave per output row, all images looped inside so each
+// weight row is read once per launch.
+constexpr int kSeMaxB = 4;  // images per pass held in registers / LDS
+
+template <typename T>
+__global__ void __launch_bounds__(256) se_fc1_kernel(const SeArgs a) {
+  extern __shared__ float smean[];  // [nb][C] means of this block's image chunk
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b0 = blockIdx.y * kSeMaxB, nb = min(kSeMaxB, a.B - b0);
+  const float invP = 1.f / (float)a.P;
+  for (int i = tid; i < nb * a.C; i += 256) {
+    const int b = b0 + i / a.C, c = i % a.C;
+    const float* p = a.pool + (size_t)b * a.ntiles * a.C + c;
+    float s = 0.f;
+    for (int t = 0; t < a.ntiles; ++t) s += p[(size_t)t * a.C];
+    smean[i] = s * invP;
+  }
+  __syncthreads();
+  const T* w1 = reinterpret_cast<const T*>(a.w1);
+  const int rows_per_block = 32;
+  for (int jj = wave; jj < rows_per_block; jj += 4) {
+    const int j = blockIdx.x * rows_per_block + jj;
+    if (j >= a.Cs) break;
+    float acc[kSeMaxB];
+#pragma unroll
+    for (int q = 0; q < kSeMaxB; ++q) acc[q] = 0.f;
+    for (int c = lane; c < a.C; c += 64) {
+      const float w = (float)w1[(size_t)j * a.C + c];
+#pragma unroll
+      for (int q = 0; q < kSeMaxB; ++q)
+        if (q < nb) acc[q] += w * smean[q * a.C + c];
+    }
+#pragma unroll
+    for (int q = 0; q < kSeMaxB; ++q) {
+      const float v = wave_sum(acc[q]);
+      if (q < nb && lane == 0) a.hid[(size_t)(b0 + q) * a.Cs + j] = relu6f(v + a.b1[j]);
+    }
+  }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) se_fc2_kernel(const SeArgs a) {
+  extern __shared__ float shid[];  // [nb][Cs]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b0 = blockIdx.y * kSeMaxB, nb = min(kSeMaxB, a.B - b0);
+  for (int i = tid; i < nb * a.Cs; i += 256) shid[i] = a.hid[(size_t)b0 * a.Cs + i];
+  __syncthreads();
+  const T* w2 = reinterpret_cast<const T*>(a.w2);
+  const int rows_per_block = 32;
+  for (int cc = wave; cc < rows_per_block; cc += 4) {
+    const int c = blockIdx.x * rows_per_block + cc;
+    if (c >= a.C) break;
+    float acc[kSeMaxB];
+#pragma unroll
+    for (int q = 0; q < kSeMaxB; ++q) acc[q] = 0.f;
+    for (int j = lane; j < a.Cs; j += 64) {
+      const float w = (float)w2[(size_t)c * a.Cs + j];
+#pragma unroll
+      for (int q = 0; q < kSeMaxB; ++q)
+        if (q < nb) acc[q] += w * shid[q * a.Cs + j];
+    }
+#pragma unroll
+    for (int q = 0; q < kSeMaxB; ++q) {
+      const float v = wave_sum(acc[q]);
+      if (q < nb && lane == 0) a.gate[(size_t)(b0 + q) * a.C + c] = sigmoidf(v + a.b2[c]);
+    }
+  }
+}
+
+hipError_t launch_se_fc1(int dtype, const SeArgs& a, hipStream_t s) {
+  dim3 grid((a.Cs + 31) / 32, (a.B + kSeMaxB - 1) / kSeMaxB);
+  const size_t lds = (size_t)kSeMaxB * a.C * 4;
+  switch (dtype) {
+    case 0: hipLaunchKernelGGL(se_fc1_kernel<float>, grid, dim3(256), lds, s, a); break;
+    case 1: hipLaunchKernelGGL(se_fc1_kernel<half_t>, grid, dim3(256), lds, s, a); break;
+    case 2: hipLaunchKernelGGL(se_fc1_kernel<bf16_t>, grid, dim3(256), lds, s, a); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+hipError_t launch_se_fc2(int dtype, const SeArgs& a, hipStream_t s) {
+  dim3 grid((a.C + 31) / 32, (a.B + kSeMaxB - 1) / kSeMaxB);
+  const size_t lds = (size_t)kSeMaxB * a.Cs * 4;
+  switch (dtype) {
+    case 0: hipLaunchKernelGGL(se_fc2_kernel<float>, grid, dim3(256), lds, s, a); break;
+    case 1: hipLaunchKernelGGL(se_fc2_kernel<half_t>, grid, dim3(256), lds, s, a); break;
+    case 2: hipLaunchKernelGGL(se_fc2_kernel<bf16_t>, grid, dim3(256), lds, s, a); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+// =============================================================================================
+// Time embedding: SinusoidalPosEmb (efficient_unet.py:68-76: [cos|sin], freqs exp(-ln(1e4)*i/half),
+// fp32 always) -> Linear -> SiLU -> Linear (:412-417).  One block per row.
+__global__ void __launch_bounds__(256) time_embed_kernel(const TimeArgs a) {
+  extern __shared__ float sm[];  // [dim] emb, [T] hidden
+  float* emb = sm;
+  float* hid = sm + a.dim;
+  const int r = blockIdx.x, tid = threadIdx.x;
+  const float t = (float)a.t[r];
+  const int half = a.dim / 2;
+  for (int i = tid; i < half; i += 256) {
+    const float arg = t * a.freqs[i];  // fp32 product like t[:, None].float() * freqs[None] (:74)
+    emb[i] = cosf(arg);
+    emb[half + i] = sinf(arg);
+  }
+  __syncthreads();
+  for (int j = tid; j < a.T; j += 256) {
+    float acc = a.b1[j];
+    for (int k = 0; k < a.dim; ++k) acc += a.w1[(size_t)j * a.dim + k] * emb[k];
+    hid[j] = siluf(acc);
+  }
+  __syncthreads();
+  for (int j = tid; j < a.T; j += 256) {
+    float acc = a.b3[j];
+    for (int k = 0; k < a.T; ++k) acc += a.w3[(size_t)j * a.T + k] * hid[k];
+    a.temb[(size_t)r * a.T + j] = acc;
+    a.silu_temb[(size_t)r * a.T + j] = siluf(acc);
+  }
+}
+hipError_t launch_time_embed(const TimeArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(time_embed_kernel, dim3(a.rows), dim3(256), (size_t)(a.dim + a.T) * 4, s, a);
+  return hipGetLastError();
+}
+
+// All per-block FiLM Linears (efficient_unet.py:189-192,215) concatenated along the output dim:
+// film[r][f] = bf[f] + Wf[f][:] . silu(temb[r]).  16 lanes per output row, 4 rows per wave step.
+__global__ void __launch_bounds__(256) film_kernel(const FilmArgs a) {
+  extern __shared__ float st[];  // [rows_chunk][T]
+  const int tid = threadIdx.x;
+  const int r0 = blockIdx.y * kSeMaxB, nr = min(kSeMaxB, a.rows - r0);
+  for (int i = tid; i < nr * a.T; i += 256) st[i] = a.silu_temb[(size_t)r0 * a.T + i];
+  __syncthreads();
+  const int sub = tid & 15;
+  const int f = blockIdx.x * 16 + (tid >> 4);
+  if (f >= a.F) return;  // whole 16-lane group exits together; no block-level sync follows
+  float acc[kSeMaxB];
+#pragma unroll
+  for (int q = 0; q < kSeMaxB; ++q) acc[q] = 0.f;
+  for (int k = sub; k < a.T; k += 16) {
+    const float w = a.wf[(size_t)f * a.T + k];
+#pragma unroll
+    for (int q = 0; q < kSeMaxB; ++q)
+      if (q < nr) acc[q] += w * st[q * a.T + k];
+  }
+#pragma unroll
+  for (int q = 0; q < kSeMaxB; ++q) {
+    float v = acc[q];
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    if (q < nr && sub == 0) a.film[(size_t)(r0 + q) * a.F + f] = v + a.bf[f];
+  }
+}
+hipError_t launch_film(const FilmArgs& a, hipStream_t s) {
+  dim3 grid((a.F + 15) / 16, (a.rows + kSeMaxB - 1) / kSeMaxB);
+  hipLaunchKernelGGL(film_kernel, grid, dim3(256), (size_t)kSeMaxB * a.T * 4, s, a);
+  return hipGetLastError();
+}
+
+__global__ void silu_rows_kernel(const float* in, float* out, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = siluf(in[i]);
+}
+hipError_t launch_silu_rows(const float* in, float* out, int64_t n, hipStream_t s) {
+  hipLaunchKernelGGL(silu_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, out, n);
+  return hipGetLastError();
+}
+
+// =============================================================================================
+// Linear attention core (efficient_unet.py:288-302).  qkv rows are [q | k | v], each head-major
+// (heads d) (:284-286).  phi(x) = elu(x)+1 on q and k only.
+__device__ __forceinline__ float phi(float x) { return x > 0.f ? x + 1.f : __expf(x); }
+
+// pass 1: kv[d][e] = sum_n phi(k[n][d]) v[n][e], ksum[d] = sum_n phi(k[n][d]); one block per (head, image).
+template <typename T>
+__global__ void __launch_bounds__(256) linattn_kv_kernel(const AttnArgs a) {
+  constexpr int CH = 64;  // positions per staged chunk
+  __shared__ float sk[CH][33], sv[CH][33];
+  const int h = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const int inner = a.heads * 32, ld = 3 * inner;
+  const T* base = reinterpret_cast<const T*>(a.qkv) + (size_t)b * a.N * ld;
+  const int d = tid >> 3, e0 = (tid & 7) * 4;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f}, ks = 0.f;
+  for (int n0 = 0; n0 < a.N; n0 += CH) {
+    for (int i = tid; i < CH * 32; i += 256) {
+      const int n = i >> 5, c = i & 31;
+      const T* row = base + (size_t)(n0 + n) * ld;
+      sk[n][c] = phi((float)row[inner + h * 32 + c]);
+      sv[n][c] = (float)row[2 * inner + h * 32 + c];
+    }
+    __syncthreads();
+#pragma unroll 8
+    for (int n = 0; n < CH; ++n) {
+      const float kd = sk[n][d];
+      ks += kd;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) acc[q] += kd * sv[n][e0 + q];
+    }
+    __syncthreads();
+  }
+  float* out = a.kv + (size_t)(b * a.heads + h) * 32 * 33;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) out[d * 33 + e0 + q] = acc[q];
+  if ((tid & 7) == 0) out[d * 33 + 32] = ks;
+}
+
+// pass 2: out[n][e] = sum_d phi(q[n][d]) kv[d][e] / (sum_d phi(q[n][d]) ksum[d] + 1e-6)
+template <typename T>
+__global__ void __launch_bounds__(256) linattn_out_kernel(const AttnArgs a) {
+  __shared__ float skv[32 * 33];
+  __shared__ float sq[64][33];
+  const int h = blockIdx.y, b = blockIdx.z, tid = threadIdx.x;
+  const int n0 = blockIdx.x * 64;
+  const int inner = a.heads * 32, ld = 3 * inner;
+  const float* kvp = a.kv + (size_t)(b * a.heads + h) * 32 * 33;
+  for (int i = tid; i < 32 * 33; i += 256) skv[i] = kvp[i];
+  const T* base = reinterpret_cast<const T*>(a.qkv) + (size_t)b * a.N * ld;
+  for (int i = tid; i < 64 * 32; i += 256) {
+    const int n = i >> 5, c = i & 31;
+    sq[n][c] = (n0 + n < a.N) ? phi((float)base[(size_t)(n0 + n) * ld + h * 32 + c]) : 0.f;
+  }
+  __syncthreads();
+  const int n = tid >> 2, e0 = (tid & 3) * 8;
+  if (n0 + n >= a.N) return;
+  float acc[8], den = 0.f;
+#pragma unroll
+  for (int q = 0; q < 8; ++q) acc[q] = 0.f;
+#pragma unroll 8
+  for (int d = 0; d < 32; ++d) {
+    const float qd = sq[n][d];
+    den += qd * skv[d * 33 + 32];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) acc[q] += qd * skv[d * 33 + e0 + q];
+  }
+  const float inv = 1.f / (den + 1e-6f);
+  T* o = reinterpret_cast<T*>(a.out) + ((size_t)b * a.N + n0 + n) * inner + h * 32 + e0;
+#pragma unroll
+  for (int q = 0; q < 8; ++q) o[q] = (T)(acc[q] * inv);
+}
+
+hipError_t launch_linattn_kv(int dtype, const AttnArgs& a, hipStream_t s) {
+  if (a.N % 64) return hipErrorInvalidValue;
+  dim3 grid(a.heads, a.B);
+  switch (dtype) {
+    case 0: hipLaunchKernelGGL(linattn_kv_kernel<float>, grid, dim3(256), 0, s, a); break;
+    case 1: hipLaunchKernelGGL(linattn_kv_kernel<half_t>, grid, dim3(256), 0, s, a); break;
+    case 2: hipLaunchKernelGGL(linattn_kv_kernel<bf16_t>, grid, dim3(256), 0, s, a); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+hipError_t launch_linattn_out(int dtype, const AttnArgs& a, hipStream_t s) {
+  dim3 grid((a.N + 63) / 64, a.heads, a.B);
+  switch (dtype) {
+    case 0: hipLaunchKernelGGL(linattn_out_kernel<float>, grid, dim3(256), 0, s, a); break;
+    case 1: hipLaunchKernelGGL(linattn_out_kernel<half_t>, grid, dim3(256), 0, s, a); break;
+    case 2: hipLaunchKernelGGL(linattn_out_kernel<bf16_t>, grid, dim3(256), 0, s, a); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+// =============================================================================================
+// y = x*as + ab (+res): the GroupNorm after to_out plus the attention residual
+// (efficient_unet.py:266-269,306-308).  Block = 64 rows x all channels, stats slab tile = block.
+template <typename T>
+__global__ void __launch_bounds__(256) affine_add_kernel(const AffineAddArgs a) {
+  constexpr int VEC = Elem<T>::VEC;
+  extern __shared__ float red[];  // [4 waves][2][C]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int m0 = blockIdx.x * kAffineTileRows;
+  const int img = m0 / a.P;
+  const int vpr = a.C / VEC;  // vectors per row
+  const T* x = reinterpret_cast<const T*>(a.x);
+  const T* res = reinterpret_cast<const T*>(a.res);
+  T* y = reinterpret_cast<T*>(a.y);
+  // thread owns column vectors cv = tid % 64 + k*64 ... handled by looping rows per wave:
+  // wave w processes rows w, w+4, ...; lanes stride over the row's vectors.
+  for (int i = tid; i < 2 * 4 * a.C; i += 256) red[i] = 0.f;
+  __syncthreads();
+  for (int v0 = lane; v0 < vpr; v0 += 64) {
+    float sc[VEC], sh[VEC], s1[VEC], s2[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      sc[e] = a.as[(size_t)img * a.C + v0 * VEC + e];
+      sh[e] = a.ab[(size_t)img * a.C + v0 * VEC + e];
+      s1[e] = 0.f;
+      s2[e] = 0.f;
+    }
+    for (int r = wave; r < kAffineTileRows; r += 4) {
+      const size_t o = (size_t)(m0 + r) * a.C + v0 * VEC;
+      float f[VEC];
+      ld_f32<T>(x + o, f);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) f[e] = f[e] * sc[e] + sh[e];
+      if (res) {
+        float rr[VEC];
+        ld_f32<T>(res + o, rr);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) f[e] += rr[e];
+      }
+      typename Elem<T>::vec_t ov = f32_to_vec<T>(f);
+      st_vec<T>(y + o, ov);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        const float q = (float)ov[e];
+        s1[e] += q;
+        s2[e] += q * q;
+      }
+    }
+    if (a.stats) {
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        red[(wave * 2 + 0) * a.C + v0 * VEC + e] = s1[e];
+        red[(wave * 2 + 1) * a.C + v0 * VEC + e] = s2[e];
+      }
+    }
+  }
+  if (a.stats) {
+    __syncthreads();
+    const int ntiles = a.P / kAffineTileRows, tile = (m0 % a.P) / kAffineTileRows;
+    for (int i = tid; i < 2 * a.C; i += 256) {
+      const int which = i / a.C, c = i % a.C;
+      const float t = red[(0 * 2 + which) * a.C + c] + red[(1 * 2 + which) * a.C + c] + red[(2 * 2 + which) * a.C + c] +
+                      red[(3 * 2 + which) * a.C + c];
+      a.stats[((size_t)(img * ntiles + tile) * 2 + which) * a.C + c] = t;
+    }
+  }
+}
+hipError_t launch_affine_add(int dtype, const AffineAddArgs& a, hipStream_t s) {
+  if (a.P % kAffineTileRows || a.M % a.P || a.C % 8) return hipErrorInvalidValue;
+  dim3 grid(a.M / kAffineTileRows);
+  const size_t lds = (size_t)8 * a.C * 4;
+  switch (dtype) {
+    case 0: hipLaunchKernelGGL(affine_add_kernel<float>, grid, dim3(256), lds, s, a); break;
+    case 1: hipLaunchKernelGGL(affine_add_kernel<half_t>, grid, dim3(256), lds, s, a); break;
+    case 2: hipLaunchKernelGGL(affine_add_kernel<bf16_t>, grid, dim3(256), lds, s, a); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+// =============================================================================================
+// fp32 NCHW <-> NHWC T at the single-operator boundary.  Block = 64 pixels x 32 channels through LDS.
+template <typename T>
+__global__ void __launch_bounds__(256) nchw_to_nhwc_kernel(const float* x, T* y, float* stats, int C, int P, int Csrc,
+                                                           int coff) {
+  __shared__ float sm[32 * 65];
+  const int tid = threadIdx.x;
+  const int b = blockIdx.y, p0 = blockIdx.x * 64, c0 = blockIdx.z * 32;
+  for (int i = tid; i < 32 * 64; i += 256) {
+    const int c = i >> 6, p = i & 63;
+    sm[c * 65 + p] = x[((size_t)b * Csrc + coff + c0 + c) * P + p0 + p];
+  }
+  __syncthreads();
+  for (int i = tid; i < 32 * 64; i += 256) {
+    const int p = i >> 5, c = i & 31;
+    const T v = (T)sm[c * 65 + p];
+    y[((size_t)b * P + p0 + p) * C + c0 + c] = v;
+    sm[c * 65 + p] = (float)v;  // element owned by this thread in this phase: no race
+  }
+  if (stats) {
+    __syncthreads();
+    const int ntiles = P / 64, tile = blockIdx.x;
+    if (tid < 32) {
+      float s1 = 0.f, s2 = 0.f;
+      for (int p = 0; p < 64; ++p) {
+        const float q = sm[tid * 65 + p];
+        s1 += q;
+        s2 += q * q;
+      }
+      stats[((size_t)(b * ntiles + tile) * 2 + 0) * C + c0 + tid] = s1;
+      stats[((size_t)(b * ntiles + tile) * 2 + 1) * C + c0 + tid] = s2;
+    }
+  }
+}
+template <typename T>
+__global__ void __launch_bounds__(256) nhwc_to_nchw_kernel(const T* x, float* y, int C, int P) {
+  __shared__ float sm[32 * 65];
+  const int tid = threadIdx.x;
+  const int b = blockIdx.y, p0 = blockIdx.x * 64, c0 = blockIdx.z * 32;
+  for (int i = tid; i < 32 * 64; i += 256) {
+    const int p = i >> 5, c = i & 31;
+    sm[c * 65 + p] = (float)x[((size_t)b * P + p0 + p) * C + c0 + c];
+  }
+  __syncthreads();
+  for (int i = tid; i < 32 * 64; i += 256) {
+    const int c = i >> 6, p = i & 63;
+    y[((size_t)b * C + c0 + c) * P + p0 + p] = sm[c * 65 + p];
+  }
+}
+hipError_t launch_nchw_to_nhwc(int dtype, const float* x, void* y, float* stats, int B, int C, int P, int Csrc, int coff,
+                               hipStream_t s) {
+  if (P % 64 || C % 32) return hipErrorInvalidValue;
+  dim3 grid(P / 64, B, C / 32);
+  switch (dtype) {
+    case 0: hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, grid, dim3(256), 0, s, x, (float*)y, stats, C, P, Csrc, coff); break;
+    case 1: hipLaunchKernelGGL(nchw_to_nhwc_kernel<half_t>, grid, dim3(256), 0, s, x, (half_t*)y, stats, C, P, Csrc, coff); break;
+    case 2: hipLaunchKernelGGL(nchw_to_nhwc_kernel<bf16_t>, grid, dim3(256), 0, s, x, (bf16_t*)y, stats, C, P, Csrc, coff); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+hipError_t launch_nhwc_to_nchw(int dtype, const void* x, float* y, int B, int C, int P, hipStream_t s) {
+  if (P % 64 || C % 32) return hipErrorInvalidValue;
+  dim3 grid(P / 64, B, C / 32);
+  switch (dtype) {
+    case 0: hipLaunchKernelGGL(nhwc_to_nchw_kernel<float>, grid, dim3(256), 0, s, (const float*)x, y, C, P); break;
+    case 1: hipLaunchKernelGGL(nhwc_to_nchw_kernel<half_t>, grid, dim3(256), 0, s, (const half_t*)x, y, C, P); break;
+    case 2: hipLaunchKernelGGL(nhwc_to_nchw_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)x, y, C, P); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+// =============================================================================================
+// Weight repack (load time only).
+template <typename T>
+__global__ void cvt_rows_kernel(const float* src, T* dst, int rows, int cols, int ld, int col0) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)rows * cols) return;
+  const int r = (int)(i / cols), c = (int)(i % cols);
+  dst[(size_t)r * ld + col0 + c] = (T)src[i];
+}
+hipError_t launch_cvt_rows(int dtype, const float* src, void* dst, int rows, int cols, int ld, int col0, hipStream_t s) {
+  const int64_t n = (int64_t)rows * cols;
+  dim3 grid((unsigned)((n + 255) / 256));
+  switch (dtype) {
+    case 0: hipLaunchKernelGGL(cvt_rows_kernel<float>, grid, dim3(256), 0, s, src, (float*)dst, rows, cols, ld, col0); break;
+    case 1: hipLaunchKernelGGL(cvt_rows_kernel<half_t>, grid, dim3(256), 0, s, src, (half_t*)dst, rows, cols, ld, col0); break;
+    case 2: hipLaunchKernelGGL(cvt_rows_kernel<bf16_t>, grid, dim3(256), 0, s, src, (bf16_t*)dst, rows, cols, ld, col0); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+// OIHW [O][I][3][3] -> [tap][O][I]
+template <typename T>
+__global__ void repack_conv3x3_kernel(const float* src, T* dst, int O, int I) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)O * I * 9) return;
+  const int tap = (int)(i % 9);
+  const int ci = (int)((i / 9) % I), co = (int)(i / (9 * (int64_t)I));
+  dst[((size_t)tap * O + co) * I + ci] = (T)src[i];
+}
+hipError_t launch_repack_conv3x3(int dtype, const float* src, void* dst, int O, int I, hipStream_t s) {
+  const int64_t n = (int64_t)O * I * 9;
+  dim3 grid((unsigned)((n + 255) / 256));
+  switch (dtype) {
+    case 0: hipLaunchKernelGGL(repack_conv3x3_kernel<float>, grid, dim3(256), 0, s, src, (float*)dst, O, I); break;
+    case 1: hipLaunchKernelGGL(repack_conv3x3_kernel<half_t>, grid, dim3(256), 0, s, src, (half_t*)dst, O, I); break;
+    case 2: hipLaunchKernelGGL(repack_conv3x3_kernel<bf16_t>, grid, dim3(256), 0, s, src, (bf16_t*)dst, O, I); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+__global__ void repack_dw_kernel(const float* src, float* dst, int C) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= C * 9) return;
+  const int tap = i % 9, c = i / 9;
+  dst[tap * C + c] = src[i];
+}
+hipError_t launch_repack_dw(const float* src, float* dst, int C, hipStream_t s) {
+  hipLaunchKernelGGL(repack_dw_kernel, dim3((C * 9 + 255) / 256), dim3(256), 0, s, src, dst, C);
+  return hipGetLastError();
+}
+
+// init_conv OIHW [O][I][3][3] -> [I*9][O];  final_conv OIHW [O<=4][I][3][3] -> [9][I][4] zero padded
+__global__ void repack_init_kernel(const float* src, float* dst, int O, int I) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= O * I * 9) return;
+  const int k = i % (I * 9), o = i / (I * 9);
+  dst[k * O + o] = src[i];
+}
+hipError_t launch_repack_init(const float* src, float* dst, int O, int I, hipStream_t s) {
+  hipLaunchKernelGGL(repack_init_kernel, dim3((O * I * 9 + 255) / 256), dim3(256), 0, s, src, dst, O, I);
+  return hipGetLastError();
+}
+__global__ void repack_final_kernel(const float* src, float* dst, int O, int I) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 9 * I * 4) return;
+  const int o = i & 3, ci = (i >> 2) % I, tap = (i >> 2) / I;
+  dst[i] = o < O ? src[((size_t)o * I + ci) * 9 + tap] : 0.f;
+}
+hipError_t launch_repack_final(const float* src, float* dst, int O, int I, hipStream_t s) {
+  if (O > 4) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(repack_final_kernel, dim3((9 * I * 4 + 255) / 256), dim3(256), 0, s, src, dst, O, I);
+  return hipGetLastError();
+}
+
+// =============================================================================================
+// LCMScheduler.step (lcm_scheduler.py:204-242), same operation order as the reference:
+//   x0 = (x - sb*eps)/sa  |  x0 = sa*x - sb*v ;  prev = last ? x0 : sap*x0 + sbp*noise
+__global__ void lcm_step_kernel(const float* eps, const float* x, const float* noise, float* prev, float* x0o,
+                                float* clamped, int64_t n, StepCoef c) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float e = eps[i], xv = x[i];
+  float x0;
+  if (c.vpred) x0 = __fsub_rn(__fmul_rn(c.sa, xv), __fmul_rn(c.sb, e));
+  else x0 = __fdiv_rn(__fsub_rn(xv, __fmul_rn(c.sb, e)), c.sa);
+  float p = x0;
+  if (!c.is_last) p = __fadd_rn(__fmul_rn(c.sap, x0), __fmul_rn(c.sbp, noise[i]));
+  prev[i] = p;
+  if (x0o) x0o[i] = x0;
+  if (clamped) clamped[i] = fminf(fmaxf(p, -1.f), 1.f);
+}
+hipError_t launch_lcm_step(const float* eps, const float* x, const float* noise, float* prev, float* x0,
+                           float* clamped, int64_t n, StepCoef c, hipStream_t s) {
+  if (!c.is_last && !noise) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(lcm_step_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, eps, x, noise, prev, x0,
+                     clamped, n, c);
+  return hipGetLastError();
+}
+// add_noise / get_velocity (lcm_scheduler.py:255-305)
+__global__ void add_noise_kernel(const float* x0, const float* noise, const int64_t* t, const float* acp, float* out,
+                                 int64_t per, int velocity) {
+  const int b = blockIdx.y;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= per) return;
+  const float a = acp[t[b]];
+  const float sa = sqrtf(a), sb = sqrtf(1.f - a);
+  const size_t o = (size_t)b * per + i;
+  out[o] = velocity ? __fsub_rn(__fmul_rn(sa, noise[o]), __fmul_rn(sb, x0[o]))
+                    : __fadd_rn(__fmul_rn(sa, x0[o]), __fmul_rn(sb, noise[o]));
+}
+hipError_t launch_add_noise(const float* x0, const float* noise, const int64_t* t, const float* acp, float* out, int B,
+                            int64_t per, int velocity, hipStream_t s) {
+  dim3 grid((unsigned)((per + 255) / 256), B);
+  hipLaunchKernelGGL(add_noise_kernel, grid, dim3(256), 0, s, x0, noise, t, acp, out, per, velocity);
+  return hipGetLastError();
+}
+
+}  // namespace llie

@@ -1,0 +1,153 @@
+/*
+ * llie.h -- C ABI of libllie_hip.so: the MI355X (gfx950) engine for the LCM denoising hot path of
+ * zamazincode/cv-diffusion-model.
+ *
+ * The reference has no FFI (it is pure PyTorch), so this header *defines* the native boundary that
+ * replaces its hot path.  Each entry point cites the reference interface it stands in for
+ * (paths relative to the reference root).  Conventions:
+ *   - plain pointers and sizes only; no torch types.  All tensor pointers are DEVICE pointers.
+ *   - public I/O tensors are fp32 NCHW contiguous, exactly what the reference's callers hold
+ *     (scripts/inference.py:137-145, scripts/benchmark.py:61-79); NHWC / reduced precision are
+ *     internal to the engine.
+ *   - the caller owns every activation / IO buffer and the workspace (size from
+ *     llie_workspace_bytes); the handle owns only the repacked weights.
+ *   - every function returns 0 on success, a negative llie_status on bad arguments, or a positive
+ *     hipError_t passed through.  Nothing throws.  llie_last_error() gives a message.
+ *   - launches are asynchronous on the caller's stream; no hidden synchronisation, no host reads
+ *     of device data.  A handle is not re-entrant (one stream at a time), like the reference module
+ *     (lcm_scheduler.py:163-164,245 mutate scheduler state inside enhance()).
+ */
+#ifndef LLIE_H_
+#define LLIE_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct llie_ctx llie_ctx;
+typedef void* llie_stream; /* hipStream_t */
+
+enum llie_status {
+  LLIE_OK = 0,
+  LLIE_ERR_ARG = -1,       /* null pointer / bad enum / bad size */
+  LLIE_ERR_SHAPE = -2,     /* shape not supported by the engine (e.g. image side not a multiple of 64) */
+  LLIE_ERR_CONFIG = -3,    /* topology the reference itself cannot construct (GroupNorm divisibility) */
+  LLIE_ERR_KEY = -4,       /* unknown state_dict key or wrong element count */
+  LLIE_ERR_NOT_LOADED = -5,/* forward called before every parameter was loaded */
+  LLIE_ERR_WORKSPACE = -6, /* workspace too small */
+  LLIE_ERR_NO_DEVICE = -7
+};
+
+enum llie_dtype { LLIE_F32 = 0, LLIE_F16 = 1, LLIE_BF16 = 2 };
+
+/* Which module tree a handle holds.  LLIE_UNET is the product; the others expose single reference
+ * operators (same parameter names as the reference classes) so that parity tests can be written
+ * per operator, the way the reference's modules are organised. */
+enum llie_kind {
+  LLIE_UNET = 0,   /* EfficientUNet                      efficient_unet.py:387-606 */
+  LLIE_IRB = 1,    /* InvertedResidualBlock              efficient_unet.py:134-236 */
+  LLIE_ATTN = 2,   /* LinearAttention                    efficient_unet.py:239-308 */
+  LLIE_DOWN = 3,   /* Downsample (3x3 stride-2 conv)     efficient_unet.py:360-372 */
+  LLIE_UP = 4      /* Upsample (bilinear x2 + 3x3 conv)  efficient_unet.py:375-384 */
+};
+
+/* Mirrors EfficientUNetConfig (efficient_unet.py:24-57) for LLIE_UNET; for the single-operator kinds
+ * only the fields named in the comments are read. */
+typedef struct llie_config {
+  int kind;               /* llie_kind */
+  int compute_dtype;      /* llie_dtype: storage type of activations / MFMA operand type (accumulation is fp32) */
+  int in_channels;        /* UNET: 6 (concat conditioning, low_light_diffusion.py:77); IRB/ATTN/DOWN/UP: C_in */
+  int out_channels;       /* UNET: 3; IRB: C_out */
+  int base_channels;
+  int channel_multipliers[4];
+  int num_res_blocks;
+  int expansion_ratio;
+  int time_embed_dim;     /* UNET, IRB */
+  int num_attention_heads;/* UNET, ATTN */
+  int image_size;         /* UNET: decides attention placement (efficient_unet.py:426,447,509) */
+  int attention_resolutions[2];
+} llie_config;
+
+/* LCM scheduler coefficients for one step (host values; computed by the host-side scheduler from the
+ * fp32 alpha-bar table, lcm_scheduler.py:208-242). */
+typedef struct llie_step_coef {
+  float sqrt_alpha_t, sqrt_beta_t;       /* alpha_prod_t**0.5, (1-alpha_prod_t)**0.5 */
+  float sqrt_alpha_prev, sqrt_beta_prev; /* for prev_t; ignored when is_last */
+  int   is_last;                         /* prev_t == 0 -> prev_sample = x0 (lcm_scheduler.py:228-229) */
+  int   v_prediction;                    /* 0 epsilon (:217), 1 v_prediction (:220) */
+} llie_step_coef;
+
+const char* llie_last_error(void);
+const char* llie_version(void);
+
+/* create_efficient_unet / EfficientUNet.__init__ (efficient_unet.py:403-530, 631-692).  Fails with
+ * LLIE_ERR_CONFIG for topologies whose GroupNorm the reference rejects (tiny, base). */
+int llie_create(const llie_config* cfg, llie_ctx** out);
+void llie_destroy(llie_ctx* ctx);
+
+/* state_dict introspection: number of parameters and (key, element count, shape) of each, in the
+ * reference's registration order, keys without the "unet." prefix.  `shape4` receives
+ * the tensor's shape in the reference's state_dict (ndim entries valid). */
+int llie_num_params(const llie_ctx* ctx);
+int llie_param_info(const llie_ctx* ctx, int index, char* key_buf, size_t key_cap, int64_t* numel, int* ndim,
+                    int64_t* shape4);
+
+/* nn.Module.load_state_dict, one tensor at a time (scripts/inference.py:78-79, scripts/benchmark.py:56):
+ * `src` is a DEVICE pointer to the fp32 tensor in the reference's own layout (OIHW conv weights,
+ * [out,in] Linear weights); the engine repacks it on `stream`. */
+int llie_load_param(llie_ctx* ctx, const char* key, const float* src, int64_t numel, llie_stream stream);
+int llie_params_loaded(const llie_ctx* ctx); /* 1 when every key has been loaded */
+
+/* Bytes of scratch the forward needs for a batch (UNET: spatial size = image_size; single
+ * operators: H x W given). */
+int64_t llie_workspace_bytes(llie_ctx* ctx, int batch, int height, int width);
+
+/* EfficientUNet.forward(x, timestep) (efficient_unet.py:532-606) with x given as its two concat
+ * halves (low_light_diffusion.py:222: cat([latents, low_light], 1)), both fp32 NCHW [B,3,S,S].
+ * `timesteps`: device int64[B].  uniform_t != 0 promises all B timesteps are equal (true inside
+ * enhance(), low_light_diffusion.py:218) and lets the engine evaluate the time MLPs once.
+ * `eps_out`: fp32 NCHW [B,3,S,S]. */
+int llie_unet_forward(llie_ctx* ctx, const float* latents, const float* cond, const int64_t* timesteps,
+                      int uniform_t, float* eps_out, int batch, void* workspace, int64_t workspace_bytes,
+                      llie_stream stream);
+
+/* Single-operator forward for kinds IRB / ATTN / DOWN / UP: x fp32 NCHW [B,C,H,W] -> y fp32 NCHW.
+ * `temb` (IRB only): device fp32 [B, time_embed_dim] time embedding (efficient_unet.py:203). */
+int llie_module_forward(llie_ctx* ctx, const float* x, const float* temb, float* y, int batch, int height,
+                        int width, void* workspace, int64_t workspace_bytes, llie_stream stream);
+
+/* LCMScheduler.step (lcm_scheduler.py:176-253), elementwise on fp32 [n]:
+ *   x0 = (sample - sqrt_beta_t*model_output)/sqrt_alpha_t      (epsilon)
+ *   prev = is_last ? x0 : sqrt_alpha_prev*x0 + sqrt_beta_prev*noise
+ * `noise` may be null when is_last.  `x0_out` and `clamped_out` (prev.clamp(-1,1),
+ * low_light_diffusion.py:240) are optional (null to skip). */
+int llie_lcm_step(const float* model_output, const float* sample, const float* noise, float* prev_out,
+                  float* x0_out, float* clamped_out, int64_t n, const llie_step_coef* coef, llie_stream stream);
+
+/* LCMScheduler.add_noise / get_velocity (lcm_scheduler.py:255-305): per-sample timesteps (device
+ * int64[B]) index a device fp32 alpha-bar table [num_train_timesteps]; tensors fp32 [B, per_sample]. */
+int llie_add_noise(const float* x0, const float* noise, const int64_t* timesteps, const float* alphas_cumprod,
+                   float* out, int batch, int64_t per_sample, int velocity, llie_stream stream);
+
+/* Whole denoising loop of LowLightDiffusion.enhance (low_light_diffusion.py:204-240) on one stream:
+ * `noise` is fp32 [steps,B,3,S,S] in the reference's draw order (initial latents first, then one draw
+ * per non-final step); `timesteps_dev` device int64 [steps,B]; `coefs` host array [steps].
+ * Outputs: `enhanced` [B,3,S,S] (clamped); optional `intermediates` [steps,B,3,S,S] (post-step,
+ * pre-clamp latents, :236-237) and `noise_preds` [steps,B,3,S,S]. */
+int llie_enhance(llie_ctx* ctx, const float* low_light, const float* noise, const int64_t* timesteps_dev,
+                 const llie_step_coef* coefs, int steps, float* enhanced, float* intermediates,
+                 float* noise_preds, int batch, void* workspace, int64_t workspace_bytes, llie_stream stream);
+
+/* Diagnostics: name and average device time of the kernels launched by the last forward are not kept
+ * here; use rocprofv3.  llie_algorithmic_bytes returns the roofline numerator of SURVEY.md 8d for one
+ * UNet forward of `batch` images at the handle's dtype (activation traffic + weights once). */
+int64_t llie_algorithmic_bytes(llie_ctx* ctx, int batch);
+int64_t llie_flops(llie_ctx* ctx, int batch);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LLIE_H_ */
