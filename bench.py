@@ -1,0 +1,147 @@
+#!/usr/bin/env python3
+"""Headline benchmark: images/sec of the 4-step LCM `enhance` loop, variant small, 256x256, fp16,
+batch 32 per GPU (BASELINE.json configs[1]), synthetic inputs and random-init weights.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one `LowLightDiffusion.enhance(x, 4)` call on this rank's batch (4 UNet forwards + 4
+scheduler steps), inputs already resident in HBM.  For N > 1 the driver launches one process per GPU
+with torch.distributed.run; ranks hold independent batch shards (weak scaling) and the outputs are
+collected with a single RCCL all_gather inside the timed region.  Rank 0 prints one
+JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy rate
+
+
+def cpu_baseline(variant: str, size: int, steps: int, state_dict, budget_s: float = 20.0) -> dict:
+    """The CPU oracle (a restatement of the reference's PyTorch path, pinned to reference goldens)
+    timed on this box's host cores on a bounded sample of the same workload: B=1 images, repeated
+    until ~budget_s of CPU time is spent (at least one warm-up + one timed call)."""
+    import oracle
+    ncores = os.cpu_count() or 1
+    try:
+        ncores = len(os.sched_getaffinity(0))
+    except Exception:  # noqa: BLE001
+        pass
+    torch.set_num_threads(ncores)
+    spec = oracle.make_spec(variant, size)
+    sd = {k: v.detach().cpu().float() for k, v in state_dict.items()}
+    g = torch.Generator().manual_seed(1234)
+    low = torch.rand(1, 3, size, size, generator=g) * 2 - 1
+    noise = oracle.draw_noise(1, size, steps, seed=123)
+    oracle.enhance_ref(sd, spec, low, steps, noise)  # warm-up
+    n, t0 = 0, time.perf_counter()
+    while True:
+        oracle.enhance_ref(sd, spec, low, steps, noise)
+        n += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or n >= 20:
+            break
+    return {"value": n / el, "unit": "images/sec", "cores": ncores, "kind": "port",
+            "sample": f"{n} x enhance(B=1, {variant}@{size}, {steps} steps, fp32) after 1 warm-up, torch CPU threads={ncores}"}
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=32, help="images per GPU")
+    ap.add_argument("--variant", default="small")
+    ap.add_argument("--image_size", type=int, default=256)
+    ap.add_argument("--lcm_steps", type=int, default=4)
+    ap.add_argument("--dtype", default="fp16", choices=["fp32", "fp16", "bf16"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    M = importlib.import_module("cv-diffusion-model_amd")
+    torch.manual_seed(0)
+    model = M.LowLightDiffusion(unet_variant=args.variant, image_size=args.image_size,
+                                num_inference_steps=args.lcm_steps, compute_dtype=args.dtype).to(dev).eval()
+    B, S = args.batch, args.image_size
+    g = torch.Generator().manual_seed(1234 + rank)
+    low = (torch.rand(B, 3, S, S, generator=g) * 2 - 1).to(dev)      # synthetic low-light batch, resident in HBM
+    gather_buf = torch.empty(world * B, 3, S, S, device=dev) if world > 1 else None
+
+    def step():
+        out = model.enhance(low, args.lcm_steps)                     # noise drawn on device, reference order
+        if world > 1:
+            dist.all_gather_into_tensor(gather_buf, out)              # the path's only collective
+        return out
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    images = world * B * args.steps
+    value = images / elapsed
+    line = {
+        "metric": "images/sec (whole node), 256x256 4-step LCM 'small'",
+        "value": round(value, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": args.dtype, "data": "synthetic (random-init weights, uniform low-light batch, device noise)",
+        "config": {"workload": f"variant={args.variant}, {S}x{S}, batch={B}/GPU, {args.lcm_steps} LCM steps, {args.dtype}, "
+                               f"{world}xMI355X (BASELINE configs[1] per GPU)",
+                   "global_batch": world * B, "parallelism": f"batch-shard x{world} + 1 all_gather" if world > 1 else "single GPU"},
+    }
+    if rank == 0:
+        if not args.no_roofline:
+            line["roofline"] = roofline(model, low, args, value / world)
+        if not args.no_cpu_baseline and world == 1:
+            line["cpu_baseline"] = cpu_baseline(args.variant, S, args.lcm_steps, model.state_dict())
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+
+
+def roofline(model, low, args, per_gpu_rate):
+    """Filled in once the engine exposes per-kernel event timing (see engine profiling hooks)."""
+    return None
+
+
+if __name__ == "__main__":
+    main()
