@@ -100,6 +100,11 @@ def main() -> None:
 
     for _ in range(args.warmup):
         step()
+    native = importlib.import_module("cv-diffusion-model_amd._native")
+    handle = model.unet._prepare(B, dev)[0]
+    prof_classes = native.K_DW | native.K_GEMM | native.K_CONV3 | native.K_SE
+    if rank == 0 and not args.no_roofline:
+        handle.profile_begin(prof_classes)   # HIP events on the launch stream, inside the timed region
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -128,7 +133,7 @@ def main() -> None:
     }
     if rank == 0:
         if not args.no_roofline:
-            line["roofline"] = roofline(model, low, args, value / world)
+            line["roofline"] = roofline(handle, native, args)
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(args.variant, S, args.lcm_steps, model.state_dict())
     if world > 1:
@@ -138,9 +143,30 @@ def main() -> None:
         print(json.dumps(line), flush=True)
 
 
-def roofline(model, low, args, per_gpu_rate):
-    """Filled in once the engine exposes per-kernel event timing (see engine profiling hooks)."""
-    return None
+def roofline(handle, native, args) -> dict:
+    """Roofline of the dominant kernel class, from HIP events recorded on the launch stream during the
+    timed region (engine hooks llie_profile_begin/end).  `achieved` = algorithmic bytes of the recorded
+    launches / their summed device time; the per-launch byte model is in DESIGN.md section 4
+    (depthwise: read h1 + write h2 = 2*B*P*Chid*elem; pointwise GEMM: A + out (+residual) + W)."""
+    names = {native.K_DW: "dwconv3x3_kernel", native.K_GEMM: "pw_gemm_kernel", native.K_CONV3: "conv3x3_kernel",
+             native.K_SE: "se_pool/fc1/fc2 kernels"}
+    stats = {}
+    for cls in names:
+        ms, n, nbytes = handle.profile_end(cls)
+        stats[cls] = (ms, n, nbytes)
+    dom = max(stats, key=lambda c: stats[c][0])
+    ms, n, nbytes = stats[dom]
+    achieved = nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+    out = {"bound": "hbm", "kernel": names[dom], "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+           "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+           "launches": n, "avg_launch_us": round(1e3 * ms / max(n, 1), 2),
+           "alg_bytes_per_launch": int(nbytes / max(n, 1)),
+           "classes": {names[c]: {"ms": round(v[0], 3), "launches": v[1],
+                                  "GBps": round(v[2] / (v[0] * 1e-3) / 1e9, 1) if v[0] > 0 else None}
+                       for c, v in stats.items()}}
+    # whole-forward view: SURVEY.md 8d algorithmic bytes of one UNet forward at this batch / dtype
+    out["forward_alg_bytes"] = handle.algorithmic_bytes(args.batch)
+    return out
 
 
 if __name__ == "__main__":

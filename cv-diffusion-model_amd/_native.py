@@ -22,7 +22,9 @@ EXPORTS = [
     "llie_last_error", "llie_version", "llie_create", "llie_destroy", "llie_num_params", "llie_param_info",
     "llie_load_param", "llie_params_loaded", "llie_workspace_bytes", "llie_unet_forward", "llie_module_forward",
     "llie_lcm_step", "llie_add_noise", "llie_enhance", "llie_algorithmic_bytes", "llie_flops",
+    "llie_profile_begin", "llie_profile_end",
 ]
+K_GEMM, K_DW, K_CONV3, K_SE = 1, 2, 4, 8
 
 
 class LibraryNotBuilt(RuntimeError):
@@ -81,6 +83,8 @@ def lib() -> C.CDLL:
     L.llie_algorithmic_bytes.restype = i64
     L.llie_flops.argtypes = [vp, ci]
     L.llie_flops.restype = i64
+    L.llie_profile_begin.argtypes = [vp, ci]
+    L.llie_profile_end.argtypes = [vp, ci, C.POINTER(C.c_double), C.POINTER(i64), C.POINTER(i64)]
     _lib = L
     return L
 
@@ -161,3 +165,12 @@ class Handle:
 
     def flops(self, batch: int) -> int:
         return int(self._L.llie_flops(self.h, batch))
+
+    def profile_begin(self, class_mask: int) -> None:
+        check(self._L.llie_profile_begin(self.h, class_mask), "profile_begin")
+
+    def profile_end(self, kernel_class: int):
+        """-> (total device ms, launches, algorithmic bytes) of the recorded launches of `kernel_class`."""
+        ms, n, b = C.c_double(), C.c_int64(), C.c_int64()
+        check(self._L.llie_profile_end(self.h, kernel_class, C.byref(ms), C.byref(n), C.byref(b)), "profile_end")
+        return ms.value, int(n.value), int(b.value)

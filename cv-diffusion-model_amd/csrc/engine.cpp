@@ -139,12 +139,17 @@ struct llie_ctx {
   size_t t_w1 = 0, t_b1 = 0, t_w3 = 0, t_b3 = 0, freqs = 0, film_w = 0, film_b = 0;
   int film_rows = 0;
   size_t init_w = 0, init_b = 0, fin_g = 0, fin_b = 0, fin_w = 0, fin_bias = 0;
-  // per-run state
-  hipStream_t stream = nullptr;
-  char* ws = nullptr;
-  bool dry = false;
-  int B = 0;
-  hipError_t herr = hipSuccess;
+  // per-kernel-class HIP-event profiling (llie_profile_begin / llie_profile_end)
+  int prof_mask = 0;
+  struct ProfRec { int cls; int64_t bytes; hipEvent_t e0, e1; };
+  std::vector<ProfRec> prof;
+  std::vector<hipEvent_t> event_pool;
+  hipEvent_t get_event() {
+    if (!event_pool.empty()) { hipEvent_t e = event_pool.back(); event_pool.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    return e;
+  }
 };
 
 namespace {
@@ -394,6 +399,16 @@ struct Run {
   template <typename T = void> T* p(size_t off) const { return reinterpret_cast<T*>(ws + off); }
   void chk(hipError_t e) { if (e != hipSuccess && err == hipSuccess) err = e; }
   size_t es() const { return elem_size(dt); }
+  // launch `f` bracketed by HIP events on the launch stream when its class is being profiled
+  template <typename F> void timed(int cls, int64_t bytes, F&& f) {
+    if (!(c->prof_mask & cls) || c->prof.size() >= 8192) { chk(f()); return; }
+    llie_ctx::ProfRec r{cls, bytes, c->get_event(), c->get_event()};
+    if (!r.e0 || !r.e1) { chk(f()); return; }
+    chk(hipEventRecord(r.e0, s));
+    chk(f());
+    chk(hipEventRecord(r.e1, s));
+    c->prof.push_back(r);
+  }
 
   Tens new_tens(int C, int H, int W, int ntiles) {
     Tens t;
@@ -445,7 +460,8 @@ struct Run {
       }
       g.w = wptr(w.w_expand); g.out = p(h1.off); g.stats = p<float>(h1.slab);
       g.M = M; g.N = w.hid; g.K = w.cin; g.P = P;
-      chk(launch_pw_gemm(dt, g, s));
+      timed(LLIE_K_GEMM, ((int64_t)M * (w.cin + w.hid) + (int64_t)w.hid * w.cin) * (int64_t)es(),
+            [&] { return launch_pw_gemm(dt, g, s); });
     }
     ar->free(as1); ar->free(ab1);
     // norm2 + FiLM folded into one affine
@@ -459,21 +475,24 @@ struct Run {
       DwArgs d{};
       d.in = p(h1.off); d.out = p(h2); d.as = p<float>(as2); d.ab = p<float>(ab2);
       d.w = wptr<float>(w.w_dw); d.pool = p<float>(pool); d.B = B; d.H = H; d.W = W; d.C = w.hid;
-      chk(launch_dwconv3x3(dt, d, s));
+      timed(LLIE_K_DW, 2LL * M * w.hid * (int64_t)es(), [&] { return launch_dwconv3x3(dt, d, s); });
     }
     free_tens(h1);
     ar->free(as2); ar->free(ab2);
     // SE MLP
     const size_t sehid = ar->alloc((size_t)B * w.sq * 4), gate = ar->alloc((size_t)B * w.hid * 4);
+    const size_t semean = ar->alloc((size_t)B * w.hid * 4);
     if (!dry) {
       SeArgs e{};
       e.pool = p<float>(pool); e.ntiles = dnt; e.P = P;
       e.w1 = wptr(w.se_w1); e.b1 = wptr<float>(w.se_b1); e.w2 = wptr(w.se_w2); e.b2 = wptr<float>(w.se_b2);
-      e.hid = p<float>(sehid); e.gate = p<float>(gate); e.B = B; e.C = w.hid; e.Cs = w.sq;
-      chk(launch_se_fc1(dt, e, s));
-      chk(launch_se_fc2(dt, e, s));
+      e.mean = p<float>(semean); e.hid = p<float>(sehid); e.gate = p<float>(gate); e.B = B; e.C = w.hid; e.Cs = w.sq;
+      timed(LLIE_K_SE, ((int64_t)B * dnt * w.hid * 4) + 2LL * w.hid * w.sq * (int64_t)es(), [&] {
+        hipError_t r1 = launch_se_fc1(dt, e, s);
+        return r1 != hipSuccess ? r1 : launch_se_fc2(dt, e, s);
+      });
     }
-    ar->free(pool); ar->free(sehid);
+    ar->free(pool); ar->free(sehid); ar->free(semean);
     // K3: project with SE gate prologue (+ skip conv as extra K segments, or identity residual)
     Tens y = new_tens(w.cout, H, W, P / BM);
     if (!dry) {
@@ -490,7 +509,8 @@ struct Run {
       }
       g.w = wptr(w.w_proj); g.out = p(y.off); g.stats = p<float>(y.slab);
       g.M = M; g.N = w.cout; g.P = P;
-      chk(launch_pw_gemm(dt, g, s));
+      timed(LLIE_K_GEMM, ((int64_t)M * (g.K + w.cout + (w.skip ? 0 : w.cout)) + (int64_t)w.cout * g.K) * (int64_t)es(),
+            [&] { return launch_pw_gemm(dt, g, s); });
     }
     ar->free(h2); ar->free(gate);
     return y;
@@ -550,7 +570,8 @@ struct Run {
       Conv3Args a{};
       a.in = p(x.off); a.w = wptr(w.w); a.bias = wptr<float>(w.bias); a.out = p(y.off); a.stats = p<float>(y.slab);
       a.B = B; a.Hi = x.H; a.Wi = x.W; a.Cin = w.c; a.Cout = w.c; a.mode = mode;
-      chk(launch_conv3x3(dt, a, s));
+      timed(LLIE_K_CONV3, ((int64_t)B * w.c * ((int64_t)x.H * x.W + (int64_t)Ho * Wo) + 9LL * w.c * w.c) * (int64_t)es(),
+            [&] { return launch_conv3x3(dt, a, s); });
     }
     return y;
   }
@@ -751,6 +772,8 @@ int llie_create(const llie_config* cfg, llie_ctx** out) {
 
 void llie_destroy(llie_ctx* c) {
   if (!c) return;
+  for (auto& r : c->prof) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
+  for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
   if (c->blob) (void)hipFree(c->blob);
   delete c;
 }
@@ -898,6 +921,33 @@ int llie_enhance(llie_ctx* c, const float* low, const float* noise, const int64_
     if (rc) return rc;
     cur = prev;
   }
+  return LLIE_OK;
+}
+
+int llie_profile_begin(llie_ctx* c, int class_mask) {
+  if (!c) return LLIE_ERR_ARG;
+  for (auto& r : c->prof) { c->event_pool.push_back(r.e0); c->event_pool.push_back(r.e1); }
+  c->prof.clear();
+  c->prof_mask = class_mask;
+  return LLIE_OK;
+}
+
+int llie_profile_end(llie_ctx* c, int kernel_class, double* total_ms, int64_t* launches, int64_t* alg_bytes) {
+  if (!c) return LLIE_ERR_ARG;
+  c->prof_mask = 0;
+  double ms = 0.0;
+  int64_t n = 0, bytes = 0;
+  for (auto& r : c->prof) {
+    if (!(r.cls & kernel_class)) continue;
+    hipError_t e = hipEventSynchronize(r.e1);
+    float t = 0.f;
+    if (e == hipSuccess) e = hipEventElapsedTime(&t, r.e0, r.e1);
+    if (e != hipSuccess) { set_err("profile: %s", hipGetErrorString(e)); return (int)e; }
+    ms += t; ++n; bytes += r.bytes;
+  }
+  if (total_ms) *total_ms = ms;
+  if (launches) *launches = n;
+  if (alg_bytes) *alg_bytes = bytes;
   return LLIE_OK;
 }
 

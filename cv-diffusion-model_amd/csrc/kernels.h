@@ -77,12 +77,13 @@ hipError_t launch_dwconv3x3(int dtype, const DwArgs& a, hipStream_t s);
 int dwconv_ntiles(int H, int W);
 
 // Squeeze-and-Excitation MLP (efficient_unet.py:96-100) in two launches.
-//   fc1: hid[b][j] = relu6(b1[j] + sum_c W1[j][c] * mean[b][c]),  mean = sum_tiles pool / P
+//   fc1: mean[b][c] = sum_tiles pool / P (own launch);  hid[b][j] = relu6(b1[j] + sum_c W1[j][c] * mean[b][c])
 //   fc2: gate[b][c] = sigmoid(b2[c] + sum_j W2[c][j] * hid[b][j])
 struct SeArgs {
   const float* pool; int ntiles; int P;
   const void* w1; const float* b1;  // [Cs][C] T
   const void* w2; const float* b2;  // [C][Cs] T
+  float* mean;                      // [B][C] scratch
   float* hid;                       // [B][Cs]
   float* gate;                      // [B][C]
   int B, C, Cs;

@@ -72,24 +72,35 @@ hipError_t launch_gn_finalize(const GnFinalizeArgs& a, hipStream_t s) {
 // weight row is read once per launch.
 constexpr int kSeMaxB = 4;  // images per pass held in registers / LDS
 
+// pool partials [B][ntiles][C] -> mean[B][C]: one block per (64 channels, image); wave w takes tiles
+// w, w+4, ... and the four partial sums are combined in a fixed order.
+__global__ void __launch_bounds__(256) se_pool_kernel(const SeArgs a) {
+  __shared__ float part[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane, b = blockIdx.y;
+  float s = 0.f;
+  if (c < a.C) {
+    const float* p = a.pool + (size_t)b * a.ntiles * a.C + c;
+    for (int t = wave; t < a.ntiles; t += 4) s += p[(size_t)t * a.C];
+  }
+  part[wave][lane] = s;
+  __syncthreads();
+  if (wave == 0 && c < a.C)
+    a.mean[(size_t)b * a.C + c] = (part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane]) * (1.f / (float)a.P);
+}
+
+constexpr int kSeRows = 8;  // output rows per block (2 per wave)
+
 template <typename T>
 __global__ void __launch_bounds__(256) se_fc1_kernel(const SeArgs a) {
   extern __shared__ float smean[];  // [nb][C] means of this block's image chunk
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b0 = blockIdx.y * kSeMaxB, nb = min(kSeMaxB, a.B - b0);
-  const float invP = 1.f / (float)a.P;
-  for (int i = tid; i < nb * a.C; i += 256) {
-    const int b = b0 + i / a.C, c = i % a.C;
-    const float* p = a.pool + (size_t)b * a.ntiles * a.C + c;
-    float s = 0.f;
-    for (int t = 0; t < a.ntiles; ++t) s += p[(size_t)t * a.C];
-    smean[i] = s * invP;
-  }
+  for (int i = tid; i < nb * a.C; i += 256) smean[i] = a.mean[(size_t)b0 * a.C + i];
   __syncthreads();
   const T* w1 = reinterpret_cast<const T*>(a.w1);
-  const int rows_per_block = 32;
-  for (int jj = wave; jj < rows_per_block; jj += 4) {
-    const int j = blockIdx.x * rows_per_block + jj;
+  for (int jj = wave; jj < kSeRows; jj += 4) {
+    const int j = blockIdx.x * kSeRows + jj;
     if (j >= a.Cs) break;
     float acc[kSeMaxB];
 #pragma unroll
@@ -116,9 +127,8 @@ __global__ void __launch_bounds__(256) se_fc2_kernel(const SeArgs a) {
   for (int i = tid; i < nb * a.Cs; i += 256) shid[i] = a.hid[(size_t)b0 * a.Cs + i];
   __syncthreads();
   const T* w2 = reinterpret_cast<const T*>(a.w2);
-  const int rows_per_block = 32;
-  for (int cc = wave; cc < rows_per_block; cc += 4) {
-    const int c = blockIdx.x * rows_per_block + cc;
+  for (int cc = wave; cc < kSeRows; cc += 4) {
+    const int c = blockIdx.x * kSeRows + cc;
     if (c >= a.C) break;
     float acc[kSeMaxB];
 #pragma unroll
@@ -138,7 +148,8 @@ __global__ void __launch_bounds__(256) se_fc2_kernel(const SeArgs a) {
 }
 
 hipError_t launch_se_fc1(int dtype, const SeArgs& a, hipStream_t s) {
-  dim3 grid((a.Cs + 31) / 32, (a.B + kSeMaxB - 1) / kSeMaxB);
+  hipLaunchKernelGGL(se_pool_kernel, dim3((a.C + 63) / 64, a.B), dim3(256), 0, s, a);
+  dim3 grid((a.Cs + kSeRows - 1) / kSeRows, (a.B + kSeMaxB - 1) / kSeMaxB);
   const size_t lds = (size_t)kSeMaxB * a.C * 4;
   switch (dtype) {
     case 0: hipLaunchKernelGGL(se_fc1_kernel<float>, grid, dim3(256), lds, s, a); break;
@@ -149,7 +160,7 @@ hipError_t launch_se_fc1(int dtype, const SeArgs& a, hipStream_t s) {
   return hipGetLastError();
 }
 hipError_t launch_se_fc2(int dtype, const SeArgs& a, hipStream_t s) {
-  dim3 grid((a.C + 31) / 32, (a.B + kSeMaxB - 1) / kSeMaxB);
+  dim3 grid((a.C + kSeRows - 1) / kSeRows, (a.B + kSeMaxB - 1) / kSeMaxB);
   const size_t lds = (size_t)kSeMaxB * a.Cs * 4;
   switch (dtype) {
     case 0: hipLaunchKernelGGL(se_fc2_kernel<float>, grid, dim3(256), lds, s, a); break;

@@ -141,8 +141,22 @@ int llie_enhance(llie_ctx* ctx, const float* low_light, const float* noise, cons
                  const llie_step_coef* coefs, int steps, float* enhanced, float* intermediates,
                  float* noise_preds, int batch, void* workspace, int64_t workspace_bytes, llie_stream stream);
 
-/* Diagnostics: name and average device time of the kernels launched by the last forward are not kept
- * here; use rocprofv3.  llie_algorithmic_bytes returns the roofline numerator of SURVEY.md 8d for one
+/* Per-kernel-class timing with HIP events recorded on the launch stream (what bench.py's `roofline`
+ * object is computed from).  llie_profile_begin arms recording for the classes in `class_mask`;
+ * every subsequent launch of those kernels is bracketed by an event pair (at most 8192 pairs).
+ * llie_profile_end disarms, synchronises on the recorded events and returns, for `kernel_class`, the
+ * summed device time, the launch count and the summed ALGORITHMIC bytes of those launches
+ * (activation elements the kernel must read and write once, plus its weights). */
+enum llie_kernel_class {
+  LLIE_K_GEMM = 1,  /* pw_gemm_kernel: 1x1 convs with fused prologue / epilogue */
+  LLIE_K_DW = 2,    /* dwconv3x3_kernel */
+  LLIE_K_CONV3 = 4, /* conv3x3_kernel (down / up sampling convs) */
+  LLIE_K_SE = 8     /* squeeze-excitation MLP launches */
+};
+int llie_profile_begin(llie_ctx* ctx, int class_mask);
+int llie_profile_end(llie_ctx* ctx, int kernel_class, double* total_ms, int64_t* launches, int64_t* algorithmic_bytes);
+
+/* llie_algorithmic_bytes returns the roofline numerator of SURVEY.md 8d for one
  * UNet forward of `batch` images at the handle's dtype (activation traffic + weights once). */
 int64_t llie_algorithmic_bytes(llie_ctx* ctx, int batch);
 int64_t llie_flops(llie_ctx* ctx, int batch);

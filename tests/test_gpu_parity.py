@@ -104,7 +104,7 @@ def test_operator_shapes_beyond_goldens_vs_oracle(dev):
         te = synth_input(name + ".temb", (b, 128), -1, 1)
         ref = unet_ref.irb_forward(sd, name, x, te)
         assert max_abs(blk(x.to(dev), te.to(dev)).cpu(), ref) < 1e-4 * max(1.0, ref.abs().max().item())
-    for c, hw in [(128, 32), (256, 8)]:
+    for c, hw in [(128, 32), (256, 16)]:
         name = f"x_up_{c}"
         up = fill(M.Upsample(c), name + ".", dev)
         sd = {name + "." + k: v.detach().cpu() for k, v in up.state_dict().items()}

@@ -45,14 +45,20 @@ def test_product_does_not_import_oracle():
             if f.endswith((".py", ".cpp", ".hip", ".h")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle", src, re.M), f
-    for f in ("bench.py",):
-        p = os.path.join(ROOT, f)
-        if os.path.exists(p):
-            src = open(p).read()
-            # bench.py may import the oracle only inside its cpu_baseline leg
-            for m in re.finditer(r"^\s*(from|import)\s+oracle", src, re.M):
-                before = src[:m.start()]
-                assert "def cpu_baseline" in before.rsplit("\ndef ", 1)[-1] or "def cpu_baseline" in before.split("\ndef ")[-1]
+    # bench.py may import the oracle only inside its cpu_baseline leg
+    import ast
+    tree = ast.parse(open(os.path.join(ROOT, "bench.py")).read())
+
+    def imports_oracle(node):
+        return any(isinstance(n, (ast.Import, ast.ImportFrom)) and
+                   any((a.name if isinstance(n, ast.Import) else (n.module or "")).split(".")[0] == "oracle"
+                       for a in (n.names if isinstance(n, ast.Import) else [n]))
+                   for n in ast.walk(node))
+
+    for node in tree.body:
+        if isinstance(node, ast.FunctionDef) and node.name == "cpu_baseline":
+            continue
+        assert not imports_oracle(node), getattr(node, "name", type(node).__name__)
 
 
 # ------------------------------------------------------------------ state_dict layout == reference
