@@ -1,103 +1,139 @@
-// Depthwise 3x3 convolution, NHWC, gfx950.
+// Depthwise 3x3 convolution, NHWC, gfx950 -- row-streaming form.
 //
 // Replaces, for one InvertedResidualBlock (efficient_unet.py:212-223):
 //   norm2 affine + FiLM (pre-folded into as/ab by gn_finalize) -> ReLU6 -> depthwise 3x3 (pad 1)
 //   -> the read pass of SE's AdaptiveAvgPool2d (:97) as per-tile partial sums.
-// HBM-bound: reads the 4x-expanded hidden tensor once, writes it once.  A workgroup owns an 8 x TX
-// pixel tile x (8 lanes x 16 B) channels; the (8+2) x (TX+2) halo tile is activated ONCE while being
-// staged into LDS (zero padding is applied after the activation, like the reference's conv padding),
-// then every thread walks down its column with three rolling output-row accumulators, so each staged
-// vector is read from LDS three times (once per horizontal tap) instead of nine.
+// HBM-bound: reads the 4x-expanded hidden tensor once, writes it once.
+//
+// A workgroup owns a column strip: TX pixels wide x TYL rows x (8 lanes x 16 B) channels, and streams
+// it top to bottom one input row at a time:
+//   * every thread keeps PF global loads (one 16-byte channel vector per row) in flight in registers;
+//   * an arriving row is activated ONCE (affine + ReLU6; zero padding applied after the activation,
+//     like the reference's conv padding) and parked in a 2-deep LDS row ring, (TX+2) x 8 vectors;
+//   * after one barrier each thread reads its three horizontal neighbours (3 ds_read_b128 per output)
+//     and feeds three rolling output-row accumulators, so vertical reuse lives in registers.
+// LDS per workgroup is ~9 KB, so occupancy is set by registers, not LDS; halo re-reads are 2 rows per
+// TYL and 2 columns per TX.
 #include "common.h"
 #include "kernels.h"
 
 namespace llie {
 
-constexpr int kDwTY = 8;
+constexpr int kDwPF = 4;  // rows of global loads kept in flight per thread
 
 template <typename T, int TX>
-__global__ void __launch_bounds__(8 * TX) dwconv3x3_kernel(const DwArgs a) {
+__global__ void __launch_bounds__(8 * TX) dwconv3x3_kernel(const DwArgs a, const int TYL) {
   constexpr int NT = 8 * TX;
   constexpr int VEC = Elem<T>::VEC;
   constexpr int CC = 8 * VEC;  // channels per workgroup
-  constexpr int PW = TX + 2, PH = kDwTY + 2;
+  constexpr int PW = TX + 2;
+  constexpr int PF = kDwPF;
   typedef typename Elem<T>::vec_t vec_t;
-  __shared__ vec_t tile[PH * PW * 8];
+  __shared__ vec_t ring[2][PW * 8];
   __shared__ float red[(NT / 64) * CC];
 
   const int tid = threadIdx.x, cl = tid & 7, xl = tid >> 3;
   const int tiles_x = a.W / TX;
   const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
-  const int x0 = tx * TX, y0 = ty * kDwTY;
+  const int x0 = tx * TX, y0 = ty * TYL;
   const int c0 = blockIdx.y * CC + cl * VEC;
   const int b = blockIdx.z;
-  const T* in = reinterpret_cast<const T*>(a.in) + (size_t)b * a.H * a.W * a.C;
-  T* out = reinterpret_cast<T*>(a.out) + (size_t)b * a.H * a.W * a.C;
+  const T* in = reinterpret_cast<const T*>(a.in) + (size_t)b * a.H * a.W * a.C + c0;
+  T* out = reinterpret_cast<T*>(a.out) + (size_t)b * a.H * a.W * a.C + c0;
+
+  // halo duty: threads 0..7 fetch column x0-1, threads 8..15 column x0+TX (their own channel lane)
+  const bool is_halo = tid < 16;
+  const int hx = tid < 8 ? x0 - 1 : x0 + TX;
+  const bool hx_ok = is_halo && hx >= 0 && hx < a.W;
+  const int hslot = tid < 8 ? 0 : TX + 1;
 
   float sc[VEC], sh[VEC];
+  vec_t w[9];  // weights stay packed in T (16 B per tap); see keep_packed() below
 #pragma unroll
   for (int e = 0; e < VEC; ++e) {
     sc[e] = a.as[(size_t)b * a.C + c0 + e];
     sh[e] = a.ab[(size_t)b * a.C + c0 + e];
   }
-  // ---- stage the activated halo tile (thread's channel lane is loop invariant: NT % 8 == 0)
-  for (int i = tid; i < PH * PW * 8; i += NT) {
-    const int pix = i >> 3;
-    const int py = pix / PW, px = pix % PW;
-    const int gy = y0 + py - 1, gx = x0 + px - 1;
-    vec_t v;
-    if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {
-      float f[VEC];
-      ld_f32<T>(in + ((size_t)gy * a.W + gx) * a.C + c0, f);
-#pragma unroll
-      for (int e = 0; e < VEC; ++e) f[e] = relu6f(f[e] * sc[e] + sh[e]);
-      v = f32_to_vec<T>(f);
-    } else {
-#pragma unroll
-      for (int e = 0; e < VEC; ++e) v[e] = (T)0.f;
-    }
-    tile[i] = v;
-  }
-  float w[9][VEC];
 #pragma unroll
   for (int t = 0; t < 9; ++t)
 #pragma unroll
-    for (int e = 0; e < VEC; ++e) w[t][e] = a.w[(size_t)t * a.C + c0 + e];
-  __syncthreads();
+    for (int e = 0; e < VEC; ++e) w[t][e] = (T)a.w[(size_t)t * a.C + c0 + e];
 
-  float acc[3][VEC], psum[VEC];
+  const int nrows = TYL + 2;  // input rows y0-1 .. y0+TYL
+  vec_t pre[PF], preh[PF];
+  auto issue = [&](int r, vec_t& v, vec_t& vh) {
+    const int gy = y0 - 1 + r;
+    if (r < nrows && gy >= 0 && gy < a.H) {
+      const T* row = in + (size_t)gy * a.W * a.C;
+      v = ld_vec<T>(row + (size_t)(x0 + xl) * a.C);
+      if (hx_ok) vh = ld_vec<T>(row + (size_t)hx * a.C);
+    }
+  };
+  auto activate = [&](vec_t v) {
+    float f[VEC];
+    vec_to_f32<T>(v, f);
 #pragma unroll
-  for (int e = 0; e < VEC; ++e) {
-    acc[0][e] = acc[1][e] = acc[2][e] = 0.f;
-    psum[e] = 0.f;
-  }
+    for (int e = 0; e < VEC; ++e) f[e] = relu6f(f[e] * sc[e] + sh[e]);
+    return f32_to_vec<T>(f);
+  };
+  vec_t zero;
 #pragma unroll
-  for (int r = 0; r < PH; ++r) {
-    float f[3][VEC];
+  for (int e = 0; e < VEC; ++e) zero[e] = (T)0.f;
+
 #pragma unroll
-    for (int kx = 0; kx < 3; ++kx) vec_to_f32<T>(tile[(r * PW + xl + kx) * 8 + cl], f[kx]);
-    // input row r feeds output rows o = r - ky (ky = 0..2); accumulator slot = o mod 3
+  for (int j = 0; j < PF; ++j) issue(j, pre[j], preh[j]);
+
+  float acc0[VEC], acc1[VEC], acc2[VEC], psum[VEC];
 #pragma unroll
-    for (int ky = 0; ky < 3; ++ky) {
-      const int o = r - ky;
-      if (o < 0 || o >= kDwTY) continue;
+  for (int e = 0; e < VEC; ++e) acc0[e] = acc1[e] = acc2[e] = psum[e] = 0.f;
+
+  for (int r0 = 0; r0 < nrows; r0 += PF) {
+#pragma unroll
+    for (int j = 0; j < PF; ++j) {
+      const int r = r0 + j;
+      if (r >= nrows) break;  // uniform over the workgroup
+      const int gy = y0 - 1 + r;
+      const bool row_ok = gy >= 0 && gy < a.H;
+      vec_t* buf = ring[j & 1];  // PF is even, so r & 1 == j & 1
+      buf[(xl + 1) * 8 + cl] = row_ok ? activate(pre[j]) : zero;
+      if (is_halo) buf[hslot * 8 + cl] = (row_ok && hx_ok) ? activate(preh[j]) : zero;
+      issue(r + PF, pre[j], preh[j]);
+      __syncthreads();
+      vec_t f[3];
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) f[kx] = buf[(xl + kx) * 8 + cl];
+      // Opaque touch of the packed weights inside the loop: stops LICM from hoisting their
+      // T->f32 conversion (72 VGPRs for 2-byte T), so the products below select v_fma_mix_f32.
+      if (sizeof(T) == 2) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+          u32x4& q = reinterpret_cast<u32x4&>(w[t]);
+          asm volatile("" : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]));
+        }
+      }
 #pragma unroll
       for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) acc[o % 3][e] += w[ky * 3 + kx][e] * f[kx][e];
-    }
-    const int done = r - 2;  // output row completed by this input row
-    if (done >= 0) {
-      vec_t ov = f32_to_vec<T>(acc[done % 3]);
-      st_vec<T>(out + ((size_t)(y0 + done) * a.W + x0 + xl) * a.C + c0, ov);
+        for (int e = 0; e < VEC; ++e) {
+          acc0[e] += (float)w[6 + kx][e] * (float)f[kx][e];  // ky = 2 -> output row r-2
+          acc1[e] += (float)w[3 + kx][e] * (float)f[kx][e];  // ky = 1 -> output row r-1
+          acc2[e] += (float)w[0 + kx][e] * (float)f[kx][e];  // ky = 0 -> output row r
+        }
+      if (r >= 2) {
+        vec_t ov = f32_to_vec<T>(acc0);
+        st_vec<T>(out + ((size_t)(y0 + r - 2) * a.W + x0 + xl) * a.C, ov);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) psum[e] += (float)ov[e];
+      }
 #pragma unroll
       for (int e = 0; e < VEC; ++e) {
-        psum[e] += (float)ov[e];
-        acc[done % 3][e] = 0.f;
+        acc0[e] = acc1[e];
+        acc1[e] = acc2[e];
+        acc2[e] = 0.f;
       }
     }
   }
-  // ---- SE pool partial: sum over the tile's pixels per channel (fixed order)
+  // ---- SE pool partial: sum over the strip's pixels per channel (fixed order)
   if (a.pool) {
 #pragma unroll
     for (int o = 8; o < 64; o <<= 1)
@@ -113,24 +149,25 @@ __global__ void __launch_bounds__(8 * TX) dwconv3x3_kernel(const DwArgs a) {
       float t = 0.f;
 #pragma unroll
       for (int wv = 0; wv < NT / 64; ++wv) t += red[wv * CC + tid];
-      const int ntiles = tiles_x * (a.H / kDwTY);
+      const int ntiles = tiles_x * (a.H / TYL);
       a.pool[((size_t)b * ntiles + blockIdx.x) * a.C + blockIdx.y * CC + tid] = t;
     }
   }
 }
 
 static int dw_tx(int W) { return (W % 32 == 0) ? 32 : ((W % 16 == 0) ? 16 : 8); }
-int dwconv_ntiles(int H, int W) { return (H / kDwTY) * (W / dw_tx(W)); }
+static int dw_tyl(int H) { return (H % 32 == 0) ? 32 : ((H % 16 == 0) ? 16 : 8); }
+int dwconv_ntiles(int H, int W) { return (H / dw_tyl(H)) * (W / dw_tx(W)); }
 
 template <typename T>
 static hipError_t launch_dw_t(const DwArgs& a, hipStream_t s) {
   constexpr int CC = 8 * Elem<T>::VEC;
-  if (a.C % CC || a.H % kDwTY || a.W % 8) return hipErrorInvalidValue;
-  const int tx = dw_tx(a.W);
-  dim3 grid((a.W / tx) * (a.H / kDwTY), a.C / CC, a.B);
-  if (tx == 32) hipLaunchKernelGGL((dwconv3x3_kernel<T, 32>), grid, dim3(256), 0, s, a);
-  else if (tx == 16) hipLaunchKernelGGL((dwconv3x3_kernel<T, 16>), grid, dim3(128), 0, s, a);
-  else hipLaunchKernelGGL((dwconv3x3_kernel<T, 8>), grid, dim3(64), 0, s, a);
+  if (a.C % CC || a.H % 8 || a.W % 8) return hipErrorInvalidValue;
+  const int tx = dw_tx(a.W), tyl = dw_tyl(a.H);
+  dim3 grid((a.W / tx) * (a.H / tyl), a.C / CC, a.B);
+  if (tx == 32) hipLaunchKernelGGL((dwconv3x3_kernel<T, 32>), grid, dim3(256), 0, s, a, tyl);
+  else if (tx == 16) hipLaunchKernelGGL((dwconv3x3_kernel<T, 16>), grid, dim3(128), 0, s, a, tyl);
+  else hipLaunchKernelGGL((dwconv3x3_kernel<T, 8>), grid, dim3(64), 0, s, a, tyl);
   return hipGetLastError();
 }
 

@@ -151,21 +151,13 @@ __global__ void __launch_bounds__(WM* WN * 64) pw_gemm_kernel(const GemmArgs g) 
     __syncthreads();
   }
 
-  // ---- epilogue: accumulators -> LDS (fp32) -> 16-byte row vectors (+bias, +residual, stats) -> HBM
-#pragma unroll
-  for (int i = 0; i < MI; ++i)
-#pragma unroll
-    for (int j = 0; j < NI; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = (wm * MI + i) * 32 + mfma_row(r, lane);
-        const int col = (wn * NI + j) * 32 + (lane & 31);
-        sC[row * CP + col] = acc[i][j][r];
-      }
-  __syncthreads();
-
+  // ---- epilogue: accumulators -> LDS (fp32) -> 16-byte row vectors (+bias, +residual, stats) -> HBM.
+  // One pass per 32-row MFMA block index `pi`: the C staging tile holds only WM*32 rows, which keeps the
+  // kernel's LDS footprint small enough for 4 workgroups per CU (the full-resolution layers are
+  // streaming kernels: occupancy, not MFMA rate, sets their speed).
   constexpr int VR = BN / VEC;   // vectors per output row
   constexpr int RPP = NT / VR;   // rows per pass
+  constexpr int SROWS = WM * 32; // rows staged per pass
   static_assert(NT % VR == 0 && VR <= 64, "epilogue mapping");
   const int cv = tid % VR, r0 = tid / VR;
   float bias[VEC], s1[VEC], s2[VEC];
@@ -177,26 +169,40 @@ __global__ void __launch_bounds__(WM* WN * 64) pw_gemm_kernel(const GemmArgs g) 
   }
   T* outp = reinterpret_cast<T*>(g.out);
   const T* resp = reinterpret_cast<const T*>(g.res);
-  for (int row = r0; row < BM; row += RPP) {
-    float v[VEC];
-    const float* pc = sC + row * CP + cv * VEC;
 #pragma unroll
-    for (int e = 0; e < VEC; ++e) v[e] = pc[e] + bias[e];
-    const size_t o = (size_t)(m0 + row) * g.N + n0 + cv * VEC;
-    if (resp) {
-      float rr[VEC];
-      ld_f32<T>(resp + o, rr);
+  for (int pi = 0; pi < MI; ++pi) {
+    if (pi) __syncthreads();  // previous pass fully read
 #pragma unroll
-      for (int e = 0; e < VEC; ++e) v[e] += rr[e];
-    }
-    vec_t ov = f32_to_vec<T>(v);
-    st_vec<T>(outp + o, ov);
-    if (g.stats) {
+    for (int j = 0; j < NI; ++j)
 #pragma unroll
-      for (int e = 0; e < VEC; ++e) {
-        const float q = (float)ov[e];
-        s1[e] += q;
-        s2[e] += q * q;
+      for (int r = 0; r < 16; ++r) {
+        const int row = wm * 32 + mfma_row(r, lane);
+        const int col = (wn * NI + j) * 32 + (lane & 31);
+        sC[row * CP + col] = acc[pi][j][r];
+      }
+    __syncthreads();
+    for (int srow = r0; srow < SROWS; srow += RPP) {
+      const int row = ((srow >> 5) * MI + pi) * 32 + (srow & 31);  // row inside the BM tile
+      float v[VEC];
+      const float* pc = sC + srow * CP + cv * VEC;
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) v[e] = pc[e] + bias[e];
+      const size_t o = (size_t)(m0 + row) * g.N + n0 + cv * VEC;
+      if (resp) {
+        float rr[VEC];
+        ld_f32<T>(resp + o, rr);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) v[e] += rr[e];
+      }
+      vec_t ov = f32_to_vec<T>(v);
+      st_vec<T>(outp + o, ov);
+      if (g.stats) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          const float q = (float)ov[e];
+          s1[e] += q;
+          s2[e] += q * q;
+        }
       }
     }
   }
@@ -209,7 +215,7 @@ __global__ void __launch_bounds__(WM* WN * 64) pw_gemm_kernel(const GemmArgs g) 
         s1[e] += __shfl_xor(s1[e], o, 64);
         s2[e] += __shfl_xor(s2[e], o, 64);
       }
-    float* red = sC + BM * CP;  // [waves][2][BN]
+    float* red = sC + SROWS * CP;  // [waves][2][BN]
     constexpr int NW = NT / 64;
     if (lane < VR) {
 #pragma unroll
@@ -235,7 +241,7 @@ static hipError_t launch_cfg(const GemmArgs& a, hipStream_t s) {
   constexpr int NT = WM * WN * 64;
   constexpr int PITCH = TilePitch<T>::value;
   constexpr size_t tiles = (size_t)(BM + BN) * PITCH * sizeof(T);
-  constexpr size_t ctile = (size_t)BM * (BN + 4) * 4 + (size_t)(NT / 64) * 2 * BN * 4;
+  constexpr size_t ctile = (size_t)(WM * 32) * (BN + 4) * 4 + (size_t)(NT / 64) * 2 * BN * 4;
   constexpr size_t lds = tiles > ctile ? tiles : ctile;
   static bool attr_done = false;
   if (!attr_done && lds > 48 * 1024) {

@@ -10,9 +10,11 @@ namespace llie {
 // GroupNorm finalize: slabs of per-channel (sum, sumsq) -> per-(image, channel) affine.
 // nn.GroupNorm(min(32,C), C) call sites: efficient_unet.py:170-171,263,268,528 (biased variance,
 // eps 1e-5); FiLM fold: efficient_unet.py:215-217  h*(1+scale)+shift after norm2's own affine.
-// One wave per (image, group); tile partials are fp32, the cross-tile combination is fp64.
-__global__ void __launch_bounds__(64) gn_finalize_kernel(const GnFinalizeArgs a) {
-  const int g = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+// One 4-wave block per (image, group); tile partials are fp32, the cross-tile combination is fp64
+// in a fixed order.
+__global__ void __launch_bounds__(256) gn_finalize_kernel(const GnFinalizeArgs a) {
+  __shared__ double part[2][4];
+  const int g = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int cg = a.C / a.groups;
   const int c_lo = g * cg;
   double s1 = 0.0, s2 = 0.0;
@@ -25,7 +27,7 @@ __global__ void __launch_bounds__(64) gn_finalize_kernel(const GnFinalizeArgs a)
     if (hi > lo) {
       const int w = hi - lo, total = w * src.ntiles;
       const float* base = src.slab + (size_t)b * src.ntiles * 2 * src.ch;
-      for (int i = lane; i < total; i += 64) {
+      for (int i = tid; i < total; i += 256) {
         const int t = i / w, c = lo + i % w;
         s1 += (double)base[(size_t)(t * 2 + 0) * src.ch + c];
         s2 += (double)base[(size_t)(t * 2 + 1) * src.ch + c];
@@ -35,13 +37,20 @@ __global__ void __launch_bounds__(64) gn_finalize_kernel(const GnFinalizeArgs a)
   }
   s1 = wave_sum(s1);
   s2 = wave_sum(s2);
+  if (lane == 0) {
+    part[0][wave] = s1;
+    part[1][wave] = s2;
+  }
+  __syncthreads();
+  s1 = (part[0][0] + part[0][1]) + (part[0][2] + part[0][3]);
+  s2 = (part[1][0] + part[1][1]) + (part[1][2] + part[1][3]);
   const double n = (double)cg * (double)a.P;
   const double mean = s1 / n;
   double var = s2 / n - mean * mean;
   if (var < 0.0) var = 0.0;
   const float rstd = (float)(1.0 / sqrt(var + (double)a.eps));
   const float fmean = (float)mean;
-  for (int i = lane; i < cg; i += 64) {
+  for (int i = tid; i < cg; i += 256) {
     const int c = c_lo + i;
     const float ga = a.gamma[c] * rstd;
     float sc = ga, sh = a.beta[c] - fmean * ga;
@@ -62,7 +71,7 @@ hipError_t launch_gn_finalize(const GnFinalizeArgs& a, hipStream_t s) {
   for (int i = 0; i < 2; ++i)
     if (a.src[i].slab) c += a.src[i].ch;
   if (c != a.C) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3(a.groups, a.B), dim3(64), 0, s, a);
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(a.groups, a.B), dim3(256), 0, s, a);
   return hipGetLastError();
 }
 
