@@ -22,7 +22,7 @@ EXPORTS = [
     "llie_last_error", "llie_version", "llie_create", "llie_destroy", "llie_num_params", "llie_param_info",
     "llie_load_param", "llie_params_loaded", "llie_workspace_bytes", "llie_unet_forward", "llie_module_forward",
     "llie_lcm_step", "llie_add_noise", "llie_enhance", "llie_algorithmic_bytes", "llie_flops",
-    "llie_profile_begin", "llie_profile_end",
+    "llie_profile_begin", "llie_profile_end", "llie_enhance_workspace_bytes",
 ]
 K_GEMM, K_DW, K_CONV3, K_SE = 1, 2, 4, 8
 
@@ -74,6 +74,8 @@ def lib() -> C.CDLL:
     L.llie_params_loaded.argtypes = [vp]
     L.llie_workspace_bytes.argtypes = [vp, ci, ci, ci]
     L.llie_workspace_bytes.restype = i64
+    L.llie_enhance_workspace_bytes.argtypes = [vp, ci, ci]
+    L.llie_enhance_workspace_bytes.restype = i64
     L.llie_unet_forward.argtypes = [vp, vp, vp, vp, ci, vp, ci, vp, i64, vp]
     L.llie_module_forward.argtypes = [vp, vp, vp, vp, ci, ci, ci, vp, i64, vp]
     L.llie_lcm_step.argtypes = [vp, vp, vp, vp, vp, vp, i64, C.POINTER(StepCoef), vp]
@@ -158,6 +160,12 @@ class Handle:
         n = self._L.llie_workspace_bytes(self.h, batch, h, w)
         if n < 0:
             check(int(n), "llie_workspace_bytes")
+        return int(n)
+
+    def enhance_workspace_bytes(self, batch: int, max_steps: int) -> int:
+        n = self._L.llie_enhance_workspace_bytes(self.h, batch, max_steps)
+        if n < 0:
+            check(int(n), "llie_enhance_workspace_bytes")
         return int(n)
 
     def algorithmic_bytes(self, batch: int) -> int:

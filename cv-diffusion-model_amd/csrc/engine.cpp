@@ -10,6 +10,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -139,6 +140,9 @@ struct llie_ctx {
   size_t t_w1 = 0, t_b1 = 0, t_w3 = 0, t_b3 = 0, freqs = 0, film_w = 0, film_b = 0;
   int film_rows = 0;
   size_t init_w = 0, init_b = 0, fin_g = 0, fin_b = 0, fin_w = 0, fin_bias = 0;
+  // hipGraph cache of llie_enhance launch sequences (key -> executable graph)
+  struct GraphEntry { bool seen = false; hipGraphExec_t exec = nullptr; hipGraph_t graph = nullptr; };
+  std::map<std::string, GraphEntry> graphs;
   // per-kernel-class HIP-event profiling (llie_profile_begin / llie_profile_end)
   int prof_mask = 0;
   struct ProfRec { int cls; int64_t bytes; hipEvent_t e0, e1; };
@@ -772,6 +776,10 @@ int llie_create(const llie_config* cfg, llie_ctx** out) {
 
 void llie_destroy(llie_ctx* c) {
   if (!c) return;
+  for (auto& kv : c->graphs) {
+    if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
+    if (kv.second.graph) (void)hipGraphDestroy(kv.second.graph);
+  }
   for (auto& r : c->prof) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
   for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
   if (c->blob) (void)hipFree(c->blob);
@@ -838,6 +846,16 @@ int64_t llie_workspace_bytes(llie_ctx* c, int batch, int height, int width) {
   return (int64_t)ar.high;
 }
 
+// Workspace for llie_enhance with room for the hipGraph staging area (inputs/outputs of up to
+// `max_steps` steps with intermediates and noise predictions).
+int64_t llie_enhance_workspace_bytes(llie_ctx* c, int batch, int max_steps) {
+  if (!c || batch <= 0 || max_steps <= 0 || c->cfg.kind != LLIE_UNET) return LLIE_ERR_ARG;
+  const int64_t core = llie_workspace_bytes(c, batch, 0, 0);
+  if (core < 0) return core;
+  const size_t img = align_up((size_t)batch * 3 * c->cfg.image_size * c->cfg.image_size * 4, 256);
+  return core + (int64_t)((2 + 3 * (size_t)max_steps) * img + align_up((size_t)max_steps * batch * 8, 256));
+}
+
 int llie_unet_forward(llie_ctx* c, const float* lat, const float* cond, const int64_t* t, int uniform_t, float* eps,
                       int batch, void* ws, int64_t ws_bytes, llie_stream stream) {
   if (!c || !lat || !cond || !t || !eps || !ws || batch <= 0 || c->cfg.kind != LLIE_UNET) return LLIE_ERR_ARG;
@@ -895,16 +913,15 @@ int llie_add_noise(const float* x0, const float* noise, const int64_t* t, const 
   return LLIE_OK;
 }
 
-int llie_enhance(llie_ctx* c, const float* low, const float* noise, const int64_t* t_dev, const llie_step_coef* coefs,
-                 int steps, float* enhanced, float* inter, float* preds, int batch, void* ws, int64_t ws_bytes,
-                 llie_stream stream) {
-  if (!c || !low || !noise || !t_dev || !coefs || !enhanced || !ws || steps <= 0 || batch <= 0 || c->cfg.kind != LLIE_UNET)
-    return LLIE_ERR_ARG;
+// The launch sequence of LowLightDiffusion.enhance (low_light_diffusion.py:204-240): `steps` x
+// (UNet forward, scheduler step).  `base` holds two latent ping-pong images and one eps image,
+// followed by the UNet workspace.
+static int enhance_sequence(llie_ctx* c, const float* low, const float* noise, const int64_t* t_dev,
+                            const llie_step_coef* coefs, int steps, float* enhanced, float* inter, float* preds,
+                            int batch, char* base, int64_t ws_bytes, llie_stream stream) {
   const int S = c->cfg.image_size;
   const int64_t n = (int64_t)batch * 3 * S * S;
   const size_t img = align_up((size_t)n * 4, 256);
-  if ((int64_t)(3 * img) > ws_bytes) { set_err("workspace too small"); return LLIE_ERR_WORKSPACE; }
-  char* base = reinterpret_cast<char*>(ws);
   float* lat[2] = {reinterpret_cast<float*>(base), reinterpret_cast<float*>(base + img)};
   float* eps_ws = reinterpret_cast<float*>(base + 2 * img);
   void* uws = base + 3 * img;
@@ -921,6 +938,75 @@ int llie_enhance(llie_ctx* c, const float* low, const float* noise, const int64_
     if (rc) return rc;
     cur = prev;
   }
+  return LLIE_OK;
+}
+
+int llie_enhance(llie_ctx* c, const float* low, const float* noise, const int64_t* t_dev, const llie_step_coef* coefs,
+                 int steps, float* enhanced, float* inter, float* preds, int batch, void* ws, int64_t ws_bytes,
+                 llie_stream stream) {
+  if (!c || !low || !noise || !t_dev || !coefs || !enhanced || !ws || steps <= 0 || batch <= 0 || c->cfg.kind != LLIE_UNET)
+    return LLIE_ERR_ARG;
+  const int S = c->cfg.image_size;
+  const int64_t n = (int64_t)batch * 3 * S * S;
+  const size_t img = align_up((size_t)n * 4, 256);
+  if ((int64_t)(3 * img) > ws_bytes) { set_err("workspace too small"); return LLIE_ERR_WORKSPACE; }
+  char* base = reinterpret_cast<char*>(ws);
+  hipStream_t hs = reinterpret_cast<hipStream_t>(stream);
+
+  // ---- hipGraph path: the ~800 launches of a 4-step loop are launch-bound in their runs of tiny
+  // kernels (GroupNorm finalize, SE MLP).  The sequence is captured once per (shape, schedule,
+  // workspace) with every pointer inside the workspace: user tensors are staged in/out by plain
+  // async copies around the graph launch.  First use of a key runs eagerly (it also performs the
+  // one-time hipFuncSetAttribute calls, which must not happen during capture).
+  static const bool no_graph = getenv("LLIE_NO_GRAPH") != nullptr;
+  const size_t n_in = 1 + (size_t)steps;                       // low + noise draws
+  const size_t n_out = 1 + (inter ? steps : 0) + (preds ? steps : 0);
+  const size_t tbytes = align_up((size_t)steps * batch * 8, 256);
+  const size_t stage = (n_in + n_out) * img + tbytes;
+  const int64_t seq_bytes = ws_bytes - (int64_t)stage;
+  bool use_graph = !no_graph && c->prof_mask == 0 && seq_bytes >= llie_workspace_bytes(c, batch, 0, 0);
+  if (!use_graph) return enhance_sequence(c, low, noise, t_dev, coefs, steps, enhanced, inter, preds, batch, base, ws_bytes, stream);
+
+  std::string key(reinterpret_cast<const char*>(coefs), sizeof(llie_step_coef) * steps);
+  char tail[128];
+  snprintf(tail, sizeof tail, "|%d|%d|%d|%d|%p|%lld|%p", batch, steps, inter ? 1 : 0, preds ? 1 : 0, ws, (long long)ws_bytes, (void*)hs);
+  key += tail;
+  llie_ctx::GraphEntry& ge = c->graphs[key];
+  if (!ge.seen) {
+    ge.seen = true;
+    return enhance_sequence(c, low, noise, t_dev, coefs, steps, enhanced, inter, preds, batch, base, ws_bytes, stream);
+  }
+  // staging area at the tail of the workspace
+  char* st = base + seq_bytes;
+  float* s_low = reinterpret_cast<float*>(st);
+  float* s_noise = reinterpret_cast<float*>(st + img);
+  float* s_enh = reinterpret_cast<float*>(st + n_in * img);
+  float* s_inter = inter ? reinterpret_cast<float*>(st + (n_in + 1) * img) : nullptr;
+  float* s_preds = preds ? reinterpret_cast<float*>(st + (n_in + 1 + (inter ? steps : 0)) * img) : nullptr;
+  int64_t* s_t = reinterpret_cast<int64_t*>(st + (n_in + n_out) * img);
+  // NB: staged noise / inter / preds are step-major with stride `img` >= n*4; keep them dense (img == n*4 when n*4 % 256 == 0)
+  if (img != (size_t)n * 4) return enhance_sequence(c, low, noise, t_dev, coefs, steps, enhanced, inter, preds, batch, base, ws_bytes, stream);
+  hipError_t e = hipMemcpyAsync(s_low, low, (size_t)n * 4, hipMemcpyDeviceToDevice, hs);
+  if (e == hipSuccess) e = hipMemcpyAsync(s_noise, noise, (size_t)n * 4 * steps, hipMemcpyDeviceToDevice, hs);
+  if (e == hipSuccess) e = hipMemcpyAsync(s_t, t_dev, (size_t)steps * batch * 8, hipMemcpyDeviceToDevice, hs);
+  if (e != hipSuccess) { set_err("enhance staging: %s", hipGetErrorString(e)); return (int)e; }
+  if (!ge.exec) {
+    e = hipStreamBeginCapture(hs, hipStreamCaptureModeThreadLocal);
+    if (e != hipSuccess) { set_err("hipStreamBeginCapture: %s", hipGetErrorString(e)); return (int)e; }
+    const int rc = enhance_sequence(c, s_low, s_noise, s_t, coefs, steps, s_enh, s_inter, s_preds, batch, base, seq_bytes, stream);
+    hipGraph_t g = nullptr;
+    e = hipStreamEndCapture(hs, &g);
+    if (rc != LLIE_OK) { if (g) (void)hipGraphDestroy(g); return rc; }
+    if (e != hipSuccess || !g) { set_err("hipStreamEndCapture: %s", hipGetErrorString(e)); return (int)(e ? e : hipErrorUnknown); }
+    e = hipGraphInstantiate(&ge.exec, g, nullptr, nullptr, 0);
+    if (e != hipSuccess) { (void)hipGraphDestroy(g); ge.exec = nullptr; set_err("hipGraphInstantiate: %s", hipGetErrorString(e)); return (int)e; }
+    ge.graph = g;
+  }
+  e = hipGraphLaunch(ge.exec, hs);
+  if (e == hipSuccess) e = hipMemcpyAsync(enhanced, s_enh, (size_t)n * 4, hipMemcpyDeviceToDevice, hs);
+  if (e == hipSuccess && inter) e = hipMemcpyAsync(inter, s_inter, (size_t)n * 4 * steps, hipMemcpyDeviceToDevice, hs);
+  if (e == hipSuccess && preds) e = hipMemcpyAsync(preds, s_preds, (size_t)n * 4 * steps, hipMemcpyDeviceToDevice, hs);
+  if (e != hipSuccess) { set_err("enhance graph launch: %s", hipGetErrorString(e)); return (int)e; }
   return LLIE_OK;
 }
 

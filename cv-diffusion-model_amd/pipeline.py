@@ -118,7 +118,7 @@ class LowLightDiffusion(nn.Module):
         enhanced = torch.empty(b, 3, s, s, dtype=torch.float32, device=device)
         inter = torch.empty(steps, b, 3, s, s, dtype=torch.float32, device=device) if return_intermediate else None
         preds = torch.empty(steps, b, 3, s, s, dtype=torch.float32, device=device) if return_noise_pred else None
-        h, ws, nbytes = self.unet._prepare(b, device)
+        h, ws, nbytes = self.unet._prepare(b, device, enhance_steps=max(steps, 8))
         with torch.cuda.device(device):
             N.check(N.lib().llie_enhance(
                 h.h, low.data_ptr(), noise_t.data_ptr(), t_dev.data_ptr(), coefs, steps, enhanced.data_ptr(),

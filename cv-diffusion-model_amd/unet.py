@@ -255,10 +255,11 @@ class EfficientUNet(_NativeModule):
         self.config = config
 
     # -- native entry points used by the pipeline ----------------------------------------------
-    def _prepare(self, batch: int, device: torch.device):
+    def _prepare(self, batch: int, device: torch.device, enhance_steps: int = 0):
         h = self._handle(resolve_compute_dtype(self.compute_dtype))
-        nbytes = h.workspace_bytes(batch)
-        return h, self._workspace(h, nbytes, device), nbytes
+        nbytes = h.enhance_workspace_bytes(batch, enhance_steps) if enhance_steps else h.workspace_bytes(batch)
+        ws = self._workspace(h, nbytes, device)
+        return h, ws, ws.numel()
 
     def forward_split(self, latents: torch.Tensor, cond: torch.Tensor, timestep: torch.Tensor,
                       uniform_t: bool = False, out: Optional[torch.Tensor] = None) -> torch.Tensor:

@@ -104,6 +104,9 @@ int llie_params_loaded(const llie_ctx* ctx); /* 1 when every key has been loaded
 /* Bytes of scratch the forward needs for a batch (UNET: spatial size = image_size; single
  * operators: H x W given). */
 int64_t llie_workspace_bytes(llie_ctx* ctx, int batch, int height, int width);
+/* Workspace for llie_enhance including the staging area its hipGraph path needs (inputs / outputs of
+ * up to `max_steps` steps).  With only llie_workspace_bytes() the loop runs as plain launches. */
+int64_t llie_enhance_workspace_bytes(llie_ctx* ctx, int batch, int max_steps);
 
 /* EfficientUNet.forward(x, timestep) (efficient_unet.py:532-606) with x given as its two concat
  * halves (low_light_diffusion.py:222: cat([latents, low_light], 1)), both fp32 NCHW [B,3,S,S].
@@ -136,7 +139,11 @@ int llie_add_noise(const float* x0, const float* noise, const int64_t* timesteps
  * `noise` is fp32 [steps,B,3,S,S] in the reference's draw order (initial latents first, then one draw
  * per non-final step); `timesteps_dev` device int64 [steps,B]; `coefs` host array [steps].
  * Outputs: `enhanced` [B,3,S,S] (clamped); optional `intermediates` [steps,B,3,S,S] (post-step,
- * pre-clamp latents, :236-237) and `noise_preds` [steps,B,3,S,S]. */
+ * pre-clamp latents, :236-237) and `noise_preds` [steps,B,3,S,S].
+ * When the workspace has llie_enhance_workspace_bytes() the launch sequence is captured into a hipGraph
+ * on its second use for a given (batch, schedule, workspace, stream) and replayed afterwards; user
+ * tensors are staged through the workspace so the graph's pointers never change
+ * (LLIE_NO_GRAPH=1 in the environment disables this). */
 int llie_enhance(llie_ctx* ctx, const float* low_light, const float* noise, const int64_t* timesteps_dev,
                  const llie_step_coef* coefs, int steps, float* enhanced, float* intermediates,
                  float* noise_preds, int batch, void* workspace, int64_t workspace_bytes, llie_stream stream);
