@@ -143,6 +143,7 @@ struct llie_ctx {
   // hipGraph cache of llie_enhance launch sequences (key -> executable graph)
   struct GraphEntry { bool seen = false; hipGraphExec_t exec = nullptr; hipGraph_t graph = nullptr; };
   std::map<std::string, GraphEntry> graphs;
+  hipStream_t cap_stream = nullptr;  // side stream used only to record captures (the legacy null stream cannot capture)
   // per-kernel-class HIP-event profiling (llie_profile_begin / llie_profile_end)
   int prof_mask = 0;
   struct ProfRec { int cls; int64_t bytes; hipEvent_t e0, e1; };
@@ -780,6 +781,7 @@ void llie_destroy(llie_ctx* c) {
     if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
     if (kv.second.graph) (void)hipGraphDestroy(kv.second.graph);
   }
+  if (c->cap_stream) (void)hipStreamDestroy(c->cap_stream);
   for (auto& r : c->prof) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
   for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
   if (c->blob) (void)hipFree(c->blob);
@@ -969,7 +971,7 @@ int llie_enhance(llie_ctx* c, const float* low, const float* noise, const int64_
 
   std::string key(reinterpret_cast<const char*>(coefs), sizeof(llie_step_coef) * steps);
   char tail[128];
-  snprintf(tail, sizeof tail, "|%d|%d|%d|%d|%p|%lld|%p", batch, steps, inter ? 1 : 0, preds ? 1 : 0, ws, (long long)ws_bytes, (void*)hs);
+  snprintf(tail, sizeof tail, "|%d|%d|%d|%d|%p|%lld", batch, steps, inter ? 1 : 0, preds ? 1 : 0, ws, (long long)ws_bytes);
   key += tail;
   llie_ctx::GraphEntry& ge = c->graphs[key];
   if (!ge.seen) {
@@ -991,11 +993,16 @@ int llie_enhance(llie_ctx* c, const float* low, const float* noise, const int64_
   if (e == hipSuccess) e = hipMemcpyAsync(s_t, t_dev, (size_t)steps * batch * 8, hipMemcpyDeviceToDevice, hs);
   if (e != hipSuccess) { set_err("enhance staging: %s", hipGetErrorString(e)); return (int)e; }
   if (!ge.exec) {
-    e = hipStreamBeginCapture(hs, hipStreamCaptureModeThreadLocal);
+    if (!c->cap_stream) {
+      e = hipStreamCreateWithFlags(&c->cap_stream, hipStreamNonBlocking);
+      if (e != hipSuccess) { set_err("hipStreamCreate: %s", hipGetErrorString(e)); return (int)e; }
+    }
+    e = hipStreamBeginCapture(c->cap_stream, hipStreamCaptureModeThreadLocal);
     if (e != hipSuccess) { set_err("hipStreamBeginCapture: %s", hipGetErrorString(e)); return (int)e; }
-    const int rc = enhance_sequence(c, s_low, s_noise, s_t, coefs, steps, s_enh, s_inter, s_preds, batch, base, seq_bytes, stream);
+    const int rc = enhance_sequence(c, s_low, s_noise, s_t, coefs, steps, s_enh, s_inter, s_preds, batch, base, seq_bytes,
+                                    reinterpret_cast<llie_stream>(c->cap_stream));
     hipGraph_t g = nullptr;
-    e = hipStreamEndCapture(hs, &g);
+    e = hipStreamEndCapture(c->cap_stream, &g);
     if (rc != LLIE_OK) { if (g) (void)hipGraphDestroy(g); return rc; }
     if (e != hipSuccess || !g) { set_err("hipStreamEndCapture: %s", hipGetErrorString(e)); return (int)(e ? e : hipErrorUnknown); }
     e = hipGraphInstantiate(&ge.exec, g, nullptr, nullptr, 0);
