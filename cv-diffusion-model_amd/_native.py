@@ -23,8 +23,14 @@ EXPORTS = [
     "llie_load_param", "llie_params_loaded", "llie_workspace_bytes", "llie_unet_forward", "llie_module_forward",
     "llie_lcm_step", "llie_add_noise", "llie_enhance", "llie_algorithmic_bytes", "llie_flops",
     "llie_profile_begin", "llie_profile_end", "llie_enhance_workspace_bytes",
+    "llie_pw_gemm", "llie_pw_gemm_tile_rows", "llie_dwconv3x3", "llie_dwconv3x3_tiles", "llie_tune",
 ]
 K_GEMM, K_DW, K_CONV3, K_SE = 1, 2, 4, 8
+
+
+class GemmSeg(C.Structure):
+    _fields_ = [("ptr", C.c_void_p), ("channels", C.c_int), ("scale", C.c_void_p), ("bias", C.c_void_p),
+                ("affine_ld", C.c_int), ("act", C.c_int)]
 
 
 class LibraryNotBuilt(RuntimeError):
@@ -85,6 +91,11 @@ def lib() -> C.CDLL:
     L.llie_algorithmic_bytes.restype = i64
     L.llie_flops.argtypes = [vp, ci]
     L.llie_flops.restype = i64
+    L.llie_pw_gemm.argtypes = [ci, C.POINTER(GemmSeg), ci, vp, vp, vp, vp, vp, ci, ci, ci, vp]
+    L.llie_pw_gemm_tile_rows.argtypes = [ci]
+    L.llie_dwconv3x3.argtypes = [ci, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, vp]
+    L.llie_dwconv3x3_tiles.argtypes = [ci, ci]
+    L.llie_tune.argtypes = [C.c_char_p, ci]
     L.llie_profile_begin.argtypes = [vp, ci]
     L.llie_profile_end.argtypes = [vp, ci, C.POINTER(C.c_double), C.POINTER(i64), C.POINTER(i64)]
     _lib = L

@@ -1017,6 +1017,43 @@ int llie_enhance(llie_ctx* c, const float* low, const float* noise, const int64_
   return LLIE_OK;
 }
 
+// ---- kernel-level entry points (unit tests, tuning): thin wrappers over the launch API
+int llie_pw_gemm(int dtype, const llie_gemm_seg* segs, int nseg, const void* w, const float* bias, const void* residual,
+                 void* out, float* stats, int M, int N, int P, llie_stream stream) {
+  if (!segs || nseg < 1 || nseg > 3 || !w || !out || dtype < 0 || dtype > 2) return LLIE_ERR_ARG;
+  GemmArgs g{};
+  g.nseg = nseg;
+  for (int i = 0; i < nseg; ++i) {
+    g.seg[i] = GemmSeg{segs[i].ptr, segs[i].channels, segs[i].scale, segs[i].bias, segs[i].affine_ld, segs[i].act};
+    g.K += segs[i].channels;
+  }
+  g.w = w; g.bias = bias; g.res = residual; g.out = out; g.stats = stats; g.M = M; g.N = N; g.P = P;
+  hipError_t e = launch_pw_gemm(dtype, g, reinterpret_cast<hipStream_t>(stream));
+  if (e == hipErrorInvalidValue) { set_err("pw_gemm: shape outside the kernel contract"); return LLIE_ERR_SHAPE; }
+  if (e != hipSuccess) { set_err("pw_gemm: %s", hipGetErrorString(e)); return (int)e; }
+  return LLIE_OK;
+}
+
+int llie_dwconv3x3(int dtype, const void* in, void* out, const float* scale, const float* bias, const float* w9c,
+                   float* pool, int B, int H, int W, int C, llie_stream stream) {
+  if (!in || !out || !scale || !bias || !w9c || dtype < 0 || dtype > 2) return LLIE_ERR_ARG;
+  DwArgs d{};
+  d.in = in; d.out = out; d.as = scale; d.ab = bias; d.w = w9c; d.pool = pool; d.B = B; d.H = H; d.W = W; d.C = C;
+  hipError_t e = launch_dwconv3x3(dtype, d, reinterpret_cast<hipStream_t>(stream));
+  if (e == hipErrorInvalidValue) { set_err("dwconv3x3: shape outside the kernel contract"); return LLIE_ERR_SHAPE; }
+  if (e != hipSuccess) { set_err("dwconv3x3: %s", hipGetErrorString(e)); return (int)e; }
+  return LLIE_OK;
+}
+
+int llie_dwconv3x3_tiles(int H, int W) { return dwconv_ntiles(H, W); }
+int llie_pw_gemm_tile_rows(int P) { return pw_gemm_tile_rows(P); }
+
+int llie_tune(const char* knob, int value) {
+  if (!knob) return LLIE_ERR_ARG;
+  if (!strcmp(knob, "gemm_bk")) { pw_gemm_force_bk(value); return LLIE_OK; }
+  return LLIE_ERR_ARG;
+}
+
 int llie_profile_begin(llie_ctx* c, int class_mask) {
   if (!c) return LLIE_ERR_ARG;
   for (auto& r : c->prof) { c->event_pool.push_back(r.e0); c->event_pool.push_back(r.e1); }

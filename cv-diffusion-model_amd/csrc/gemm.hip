@@ -15,12 +15,12 @@
 
 namespace llie {
 
-template <typename T, int BM, int BN, int WM, int WN>
+template <typename T, int BM, int BN, int WM, int WN, int BK>
 __global__ void __launch_bounds__(WM* WN * 64) pw_gemm_kernel(const GemmArgs g) {
   constexpr int NT = WM * WN * 64;
   constexpr int VEC = Elem<T>::VEC;
-  constexpr int VPR = 32 / VEC;  // 16-byte vectors per 32-wide k-chunk row
-  constexpr int PITCH = TilePitch<T>::value;
+  constexpr int VPR = BK / VEC;  // 16-byte vectors per BK-wide k-chunk row
+  constexpr int PITCH = BK + VEC;  // one 16-byte pad per row: conflict-free ds_read_b128 (80/144/272-byte rows)
   constexpr int MI = BM / (WM * 32), NI = BN / (WN * 32);
   constexpr int A_VECS = BM * VPR, B_VECS = BN * VPR;
   constexpr int A_PER = (A_VECS + NT - 1) / NT, B_PER = (B_VECS + NT - 1) / NT;
@@ -124,30 +124,33 @@ __global__ void __launch_bounds__(WM* WN * 64) pw_gemm_kernel(const GemmArgs g) 
     }
   };
 
-  const int nchunks = g.K / 32;
+  const int nchunks = g.K / BK;
   prefetch(0);
   for (int c = 0; c < nchunks; ++c) {
     stage();
     __syncthreads();
-    if (c + 1 < nchunks) prefetch((c + 1) * 32);
-    T fa[MI][16], fb[NI][16];
+    if (c + 1 < nchunks) prefetch((c + 1) * BK);
     const int lr = lane & 31, lk = (lane >> 5) * 16;
 #pragma unroll
-    for (int i = 0; i < MI; ++i) {
-      const T* p = sA + ((wm * MI + i) * 32 + lr) * PITCH + lk;
+    for (int sub = 0; sub < BK / 32; ++sub) {
+      T fa[MI][16], fb[NI][16];
 #pragma unroll
-      for (int q = 0; q < 16 / VEC; ++q) *reinterpret_cast<vec_t*>(&fa[i][q * VEC]) = *reinterpret_cast<const vec_t*>(p + q * VEC);
+      for (int i = 0; i < MI; ++i) {
+        const T* p = sA + ((wm * MI + i) * 32 + lr) * PITCH + sub * 32 + lk;
+#pragma unroll
+        for (int q = 0; q < 16 / VEC; ++q) *reinterpret_cast<vec_t*>(&fa[i][q * VEC]) = *reinterpret_cast<const vec_t*>(p + q * VEC);
+      }
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        const T* p = sB + ((wn * NI + j) * 32 + lr) * PITCH + sub * 32 + lk;
+#pragma unroll
+        for (int q = 0; q < 16 / VEC; ++q) *reinterpret_cast<vec_t*>(&fb[j][q * VEC]) = *reinterpret_cast<const vec_t*>(p + q * VEC);
+      }
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) Mfma<T>::chunk(fa[i], fb[j], acc[i][j]);
     }
-#pragma unroll
-    for (int j = 0; j < NI; ++j) {
-      const T* p = sB + ((wn * NI + j) * 32 + lr) * PITCH + lk;
-#pragma unroll
-      for (int q = 0; q < 16 / VEC; ++q) *reinterpret_cast<vec_t*>(&fb[j][q * VEC]) = *reinterpret_cast<const vec_t*>(p + q * VEC);
-    }
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-      for (int j = 0; j < NI; ++j) Mfma<T>::chunk(fa[i], fb[j], acc[i][j]);
     __syncthreads();
   }
 
@@ -236,39 +239,46 @@ __global__ void __launch_bounds__(WM* WN * 64) pw_gemm_kernel(const GemmArgs g) 
   }
 }
 
-template <typename T, int BM, int BN, int WM, int WN>
+template <typename T, int BM, int BN, int WM, int WN, int BK>
 static hipError_t launch_cfg(const GemmArgs& a, hipStream_t s) {
   constexpr int NT = WM * WN * 64;
-  constexpr int PITCH = TilePitch<T>::value;
+  constexpr int PITCH = BK + Elem<T>::VEC;
   constexpr size_t tiles = (size_t)(BM + BN) * PITCH * sizeof(T);
   constexpr size_t ctile = (size_t)(WM * 32) * (BN + 4) * 4 + (size_t)(NT / 64) * 2 * BN * 4;
   constexpr size_t lds = tiles > ctile ? tiles : ctile;
   static bool attr_done = false;
   if (!attr_done && lds > 48 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pw_gemm_kernel<T, BM, BN, WM, WN>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pw_gemm_kernel<T, BM, BN, WM, WN, BK>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     attr_done = true;
   }
   const unsigned grid = (unsigned)((a.M / BM) * (a.N / BN));
-  hipLaunchKernelGGL((pw_gemm_kernel<T, BM, BN, WM, WN>), dim3(grid), dim3(NT), lds, s, a);
+  hipLaunchKernelGGL((pw_gemm_kernel<T, BM, BN, WM, WN, BK>), dim3(grid), dim3(NT), lds, s, a);
   return hipGetLastError();
 }
 
 int pw_gemm_tile_rows(int P) { return (P % 128 == 0) ? 128 : 64; }
 
+// tuning knob for tools/gpu_tune.py (0 = automatic)
+static int g_force_bk = 0;
+void pw_gemm_force_bk(int bk) { g_force_bk = bk; }
+
 template <typename T>
 static hipError_t launch_t(const GemmArgs& a, hipStream_t s) {
   const int BM = pw_gemm_tile_rows(a.P);
   const int BN = (a.N % 128 == 0) ? 128 : ((a.N % 64 == 0) ? 64 : 32);
+  bool k64 = sizeof(T) == 2;  // BK = 64 needs every K segment to be a multiple of 64 (2-byte T only)
+  for (int i = 0; i < a.nseg; ++i) k64 = k64 && (a.seg[i].ch % 64 == 0);
+  if (g_force_bk == 32) k64 = false;
   if (BM == 128) {
-    if (BN == 128) return launch_cfg<T, 128, 128, 2, 2>(a, s);
-    if (BN == 64) return launch_cfg<T, 128, 64, 2, 2>(a, s);
-    return launch_cfg<T, 128, 32, 4, 1>(a, s);
+    if (BN == 128) return k64 ? launch_cfg<T, 128, 128, 2, 2, 64>(a, s) : launch_cfg<T, 128, 128, 2, 2, 32>(a, s);
+    if (BN == 64) return k64 ? launch_cfg<T, 128, 64, 2, 2, 64>(a, s) : launch_cfg<T, 128, 64, 2, 2, 32>(a, s);
+    return k64 ? launch_cfg<T, 128, 32, 4, 1, 64>(a, s) : launch_cfg<T, 128, 32, 4, 1, 32>(a, s);
   }
-  if (BN == 128) return launch_cfg<T, 64, 128, 2, 2>(a, s);
-  if (BN == 64) return launch_cfg<T, 64, 64, 2, 2>(a, s);
-  return launch_cfg<T, 64, 32, 2, 1>(a, s);
+  if (BN == 128) return launch_cfg<T, 64, 128, 2, 2, 32>(a, s);
+  if (BN == 64) return launch_cfg<T, 64, 64, 2, 2, 32>(a, s);
+  return launch_cfg<T, 64, 32, 2, 1, 32>(a, s);
 }
 
 hipError_t launch_pw_gemm(int dtype, const GemmArgs& a, hipStream_t s) {

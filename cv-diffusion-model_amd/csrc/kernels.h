@@ -43,6 +43,7 @@ struct GemmArgs {
 };
 hipError_t launch_pw_gemm(int dtype, const GemmArgs& a, hipStream_t s);
 int pw_gemm_tile_rows(int P);  // BM used for a given P (stats slab tiles = P / BM)
+void pw_gemm_force_bk(int bk);  // tuning knob (0 = automatic)
 
 // GroupNorm statistics -> per-(image, channel) affine tables.
 //   mean/var over groups of cg = C/32 channels x P pixels from up to two slabs (virtual concat),

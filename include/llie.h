@@ -148,6 +148,26 @@ int llie_enhance(llie_ctx* ctx, const float* low_light, const float* noise, cons
                  const llie_step_coef* coefs, int steps, float* enhanced, float* intermediates,
                  float* noise_preds, int batch, void* workspace, int64_t workspace_bytes, llie_stream stream);
 
+/* ---- Kernel-level entry points (unit tests and tuning; SURVEY.md 8b "per-kernel entry points").
+ * Activations are NHWC rows in the compute dtype T (llie_dtype); see DESIGN.md section 3.
+ *
+ * llie_pw_gemm: out[M][N] = sum over K-segments act(A_seg * scale + bias) . W[N][K]^T (+bias[N]) (+residual)
+ *   -- the 1x1 convolutions efficient_unet.py:174,186,199,265-267 with their fused prologue/epilogue.
+ *   scale/bias of a segment are fp32 [M/P][affine_ld] tables (null = identity); act: 0 none, 1 ReLU6.
+ *   stats (optional): fp32 slab [M/P][P/tile_rows][2][N] of per-channel (sum, sum of squares).
+ * llie_dwconv3x3: out = depthwise3x3(relu6(in*scale+bias)), weights fp32 [9][C] tap-major
+ *   (efficient_unet.py:212-220); pool (optional): fp32 [B][tiles][C] partial sums for the SE average pool. */
+typedef struct llie_gemm_seg {
+  const void* ptr; int channels; const float* scale; const float* bias; int affine_ld; int act;
+} llie_gemm_seg;
+int llie_pw_gemm(int dtype, const llie_gemm_seg* segs, int nseg, const void* w, const float* bias, const void* residual,
+                 void* out, float* stats, int M, int N, int P, llie_stream stream);
+int llie_pw_gemm_tile_rows(int P);
+int llie_dwconv3x3(int dtype, const void* in, void* out, const float* scale, const float* bias, const float* w9c,
+                   float* pool, int B, int H, int W, int C, llie_stream stream);
+int llie_dwconv3x3_tiles(int H, int W);
+int llie_tune(const char* knob, int value); /* tuning knobs for tools/gpu_tune.py: "gemm_bk" = 0 (auto) | 32 */
+
 /* Per-kernel-class timing with HIP events recorded on the launch stream (what bench.py's `roofline`
  * object is computed from).  llie_profile_begin arms recording for the classes in `class_mask`;
  * every subsequent launch of those kernels is bracketed by an event pair (at most 8192 pairs).

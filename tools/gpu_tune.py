@@ -1,0 +1,108 @@
+#!/usr/bin/env python3
+"""Times individual pointwise-GEMM / depthwise launches at the shapes of small@256 B=32 (GPU box)."""
+import ctypes as C
+import importlib
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+N = importlib.import_module("cv-diffusion-model_amd._native")
+L = N.lib()
+dev = torch.device("cuda:0")
+st = lambda: torch.cuda.current_stream().cuda_stream
+
+
+def time_it(fn, iters=10):
+    for _ in range(2):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e3  # us
+
+
+def gemm(kind, M, segs, Nout, P, dtype=1, B=32):
+    """kind 'k1': affine+relu6 prologue on all segs, stats; 'k3': gate on seg0, identity others, residual if 1 seg."""
+    tdt = torch.float16 if dtype == 1 else torch.float32
+    K = sum(segs)
+    a = [torch.randn(M, c, device=dev, dtype=tdt) for c in segs]
+    w = torch.randn(Nout, K, device=dev, dtype=tdt) * 0.05
+    out = torch.empty(M, Nout, device=dev, dtype=tdt)
+    sc = torch.rand(B, K, device=dev) + 0.5
+    bi = torch.randn(B, K, device=dev) * 0.1
+    tiles = P // L.llie_pw_gemm_tile_rows(P)
+    stats = torch.empty(B * tiles * 2 * Nout, device=dev)
+    res = torch.randn(M, Nout, device=dev, dtype=tdt) if (kind == "k3" and len(segs) == 1) else None
+    arr = (N.GemmSeg * len(segs))()
+    off = 0
+    for i, c in enumerate(segs):
+        if kind == "k1":
+            arr[i] = N.GemmSeg(a[i].data_ptr(), c, sc.data_ptr() + off * 4, bi.data_ptr() + off * 4, K, 1)
+        elif i == 0:
+            arr[i] = N.GemmSeg(a[i].data_ptr(), c, sc.data_ptr(), None, K, 0)
+        else:
+            arr[i] = N.GemmSeg(a[i].data_ptr(), c, None, None, 0, 0)
+        off += c
+
+    def run():
+        N.check(L.llie_pw_gemm(dtype, arr, len(segs), w.data_ptr(), None, res.data_ptr() if res is not None else None,
+                               out.data_ptr(), stats.data_ptr(), M, Nout, P, st()))
+    us = time_it(run)
+    es = 2 if dtype else 4
+    nbytes = (M * K + M * Nout * (2 if res is not None else 1)) * es
+    flops = 2.0 * M * K * Nout
+    return us, nbytes / us / 1e3, flops / us / 1e6
+
+
+def dw(B, H, C, dtype=1):
+    tdt = torch.float16 if dtype == 1 else torch.float32
+    x = torch.randn(B, H, H, C, device=dev, dtype=tdt)
+    y = torch.empty_like(x)
+    sc = torch.rand(B, C, device=dev) + 0.5
+    bi = torch.randn(B, C, device=dev) * 0.1
+    w = torch.randn(9, C, device=dev) * 0.3
+    pool = torch.empty(B * L.llie_dwconv3x3_tiles(H, H) * C, device=dev)
+
+    def run():
+        N.check(L.llie_dwconv3x3(dtype, x.data_ptr(), y.data_ptr(), sc.data_ptr(), bi.data_ptr(), w.data_ptr(),
+                                 pool.data_ptr(), B, H, H, C, st()))
+    us = time_it(run)
+    return us, 2 * x.numel() * x.element_size() / us / 1e3
+
+
+SHAPES = [  # (name, kind, P, segs, N)   small@256, B=32
+    ("enc0 K1 32->128", "k1", 65536, [32], 128), ("enc0 K3 128->32", "k3", 65536, [128], 32),
+    ("dec3.0 K1 96->384", "k1", 65536, [64, 32], 384), ("dec3.0 K3 384+96->32", "k3", 65536, [384, 64, 32], 32),
+    ("enc1.1 K1 64->256", "k1", 16384, [64], 256), ("enc1.1 K3 256->64", "k3", 16384, [256], 64),
+    ("dec2.0 K1 192->768", "k1", 16384, [128, 64], 768), ("dec2.0 K3 768+192->64", "k3", 16384, [768, 128, 64], 64),
+    ("enc2.1 K1 128->512", "k1", 4096, [128], 512), ("enc2.1 K3 512->128", "k3", 4096, [512], 128),
+    ("dec1.0 K1 384->1536", "k1", 4096, [256, 128], 1536), ("dec1.0 K3 1536+384->128", "k3", 4096, [1536, 256, 128], 128),
+    ("mid K1 256->1024", "k1", 1024, [256], 1024), ("mid K3 1024->256", "k3", 1024, [1024], 256),
+    ("dec0.0 K1 512->2048", "k1", 1024, [256, 256], 2048), ("dec0.0 K3 2048+512->256", "k3", 1024, [2048, 256, 256], 256),
+]
+
+if __name__ == "__main__":
+    B = 32
+    knobs = [("auto", 0), ("bk32", 32)]
+    print(f"{'shape':28s} " + " ".join(f"{k:>26s}" for k, _ in knobs))
+    tot = {k: 0.0 for k, _ in knobs}
+    for name, kind, P, segs, n in SHAPES:
+        row = []
+        for k, v in knobs:
+            L.llie_tune(b"gemm_bk", v)
+            us, gbs, tf = gemm(kind, B * P, segs, n, P)
+            tot[k] += us
+            row.append(f"{us:8.1f}us {gbs:6.0f}GB/s {tf:5.0f}TF")
+        print(f"{name:28s} " + " ".join(f"{r:>26s}" for r in row), flush=True)
+    print("sum(us):", {k: round(v, 1) for k, v in tot.items()})
+    L.llie_tune(b"gemm_bk", 0)
+    for H, Cc in [(256, 128), (256, 384), (128, 256), (128, 768), (64, 512), (64, 1536), (32, 1024), (32, 2048)]:
+        us, gbs = dw(B, H, Cc)
+        print(f"dw {H}x{H} C={Cc}: {us:8.1f} us  {gbs:6.0f} GB/s", flush=True)
