@@ -6,6 +6,8 @@
 //   Downsample  (efficient_unet.py:367)  3x3 stride 2       } implicit GEMM on MFMA: M = 8 x TW output pixels,
 //   Upsample    (efficient_unet.py:383-384) bilinear x2 + 3x3 } N = Cout tile, K = 9 taps x Cin; the upsampled
 //               halo patch is interpolated on the fly into LDS, so the 4x tensor never reaches HBM.
+#include <type_traits>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -83,14 +85,121 @@ __global__ void __launch_bounds__(256) init_conv_kernel(const InitConvArgs a) {
     }
   }
 }
+// ---------------------------------------------------------------------------------------------
+// init_conv on MFMA (2-byte T): im2col without a gather.  The 18x18 halo patch is staged in LDS as
+// [y][x][8 channels] (16 B per pixel; channels >= Cin are zero), and K is ordered (tap, channel8), so
+// one ds_read_b128 per k-step IS the lane's A fragment: k-step s covers taps 2s (lane half 0) and 2s+1
+// (lane half 1); tap 9 does not exist and is fed zeros.  5 k-steps (K = 80 >= 72).  Weights come
+// pre-packed as [s][half][Cout][8] T.  One wave computes two 32-pixel x 32-channel tiles per 32 output
+// channels; its fp32 tile goes through a wave-private LDS patch so stores are full 64-byte pixel rows.
+template <typename T>
+__global__ void __launch_bounds__(256) init_conv_mfma_kernel(const InitConvArgs a) {
+  typedef typename Elem<T>::vec_t vec_t;
+  constexpr int PWD = 19;
+  __shared__ vec_t patch[18 * PWD + 1];   // +1: an all-zero slot for the missing 10th tap
+  __shared__ float ctile[4][32 * 33];
+  __shared__ float red[4][2][32];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tiles_x = a.W / 16;
+  const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x, b = blockIdx.y;
+  const int x0 = tx * 16, y0 = ty * 16;
+  const int Cin = a.c0 + a.c1;
+  const size_t plane = (size_t)a.H * a.W;
+  for (int i = tid; i < 18 * PWD + 1; i += 256) {
+    const int py = i / PWD, px = i % PWD;
+    const int gy = y0 + py - 1, gx = x0 + px - 1;
+    vec_t v;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (T)0.f;
+    if (i < 18 * PWD && px < 18 && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {
+      for (int ci = 0; ci < Cin; ++ci) {
+        const float* src = ci < a.c0 ? a.x0 + ((size_t)b * a.c0 + ci) * plane : a.x1 + ((size_t)b * a.c1 + (ci - a.c0)) * plane;
+        v[ci] = (T)src[(size_t)gy * a.W + gx];
+      }
+    }
+    patch[i] = v;
+  }
+  __syncthreads();
+  const int r = lane & 31, h = lane >> 5;
+  const T* wp = reinterpret_cast<const T*>(a.wp);
+  T* out = reinterpret_cast<T*>(a.out) + (size_t)b * a.H * a.W * a.Cout;
+  const int ntiles = tiles_x * (a.H / 16);
+  float* ct = ctile[wave];
+  for (int oc0 = 0; oc0 < a.Cout; oc0 += 32) {
+    vec_t wf[5];
+#pragma unroll
+    for (int s = 0; s < 5; ++s) wf[s] = ld_vec<T>(wp + ((size_t)(s * 2 + h) * a.Cout + oc0 + r) * 8);
+    const float bias = a.bias[oc0 + r];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int g = wave * 2 + t;                 // 32-pixel group: rows 2g, 2g+1 of the 16x16 tile
+      const int py = 2 * g + (r >> 4), px = r & 15;
+      f32x16 acc;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+#pragma unroll
+      for (int s = 0; s < 5; ++s) {
+        const int tap = 2 * s + h;
+        const int idx = tap < 9 ? (py + tap / 3) * PWD + px + tap % 3 : 18 * PWD;
+        const vec_t av = patch[idx];
+        if constexpr (std::is_same<T, half_t>::value) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, wf[s], acc, 0, 0, 0);
+        else acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, wf[s], acc, 0, 0, 0);
+      }
+      // D[pixel (rows in registers)][channel = r]: + bias, round, stats, then transpose through LDS
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const float v = (float)(T)(acc[q] + bias);
+        s1 += v;
+        s2 += v * v;
+        ct[mfma_row(q, lane) * 33 + r] = v;
+      }
+      // wave-private tile: no block barrier needed, only LDS ordering within the wave
+      __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
+      __builtin_amdgcn_wave_barrier();
+      {
+        const int p = lane >> 1, half = lane & 1;        // pixel in group, 16-channel half
+        float f[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) f[e] = ct[p * 33 + half * 16 + e];
+        const int oy = y0 + 2 * g + (p >> 4), ox = x0 + (p & 15);
+        T* dst = out + ((size_t)oy * a.W + ox) * a.Cout + oc0 + half * 16;
+        st_vec<T>(dst, f32_to_vec<T>(f));
+        st_vec<T>(dst + 8, f32_to_vec<T>(f + 8));
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+    if (a.stats) {
+      s1 += __shfl_xor(s1, 32, 64);
+      s2 += __shfl_xor(s2, 32, 64);
+      if (lane < 32) {
+        red[wave][0][lane] = s1;
+        red[wave][1][lane] = s2;
+      }
+      __syncthreads();
+      if (tid < 64) {
+        const int which = tid >> 5, o = tid & 31;
+        const float tt = red[0][which][o] + red[1][which][o] + red[2][which][o] + red[3][which][o];
+        a.stats[((size_t)(b * ntiles + blockIdx.x) * 2 + which) * a.Cout + oc0 + o] = tt;
+      }
+      __syncthreads();
+    }
+  }
+}
 int init_conv_ntiles(int H, int W) { return (H / 16) * (W / 16); }
 hipError_t launch_init_conv(int dtype, const InitConvArgs& a, hipStream_t s) {
   if (a.H % 16 || a.W % 16 || a.Cout % 32 || a.c0 + a.c1 > 8) return hipErrorInvalidValue;
   dim3 grid((a.H / 16) * (a.W / 16), a.B);
   switch (dtype) {
     case 0: hipLaunchKernelGGL(init_conv_kernel<float>, grid, dim3(256), 0, s, a); break;
-    case 1: hipLaunchKernelGGL(init_conv_kernel<half_t>, grid, dim3(256), 0, s, a); break;
-    case 2: hipLaunchKernelGGL(init_conv_kernel<bf16_t>, grid, dim3(256), 0, s, a); break;
+    case 1:
+      if (a.wp) hipLaunchKernelGGL(init_conv_mfma_kernel<half_t>, grid, dim3(256), 0, s, a);
+      else hipLaunchKernelGGL(init_conv_kernel<half_t>, grid, dim3(256), 0, s, a);
+      break;
+    case 2:
+      if (a.wp) hipLaunchKernelGGL(init_conv_mfma_kernel<bf16_t>, grid, dim3(256), 0, s, a);
+      else hipLaunchKernelGGL(init_conv_kernel<bf16_t>, grid, dim3(256), 0, s, a);
+      break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();

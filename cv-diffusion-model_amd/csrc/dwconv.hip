@@ -22,7 +22,7 @@ namespace llie {
 constexpr int kDwPF = 4;  // rows of global loads kept in flight per thread
 
 template <typename T, int TX>
-__global__ void __launch_bounds__(8 * TX) dwconv3x3_kernel(const DwArgs a, const int TYL) {
+__global__ void __launch_bounds__(8 * TX) dwconv3x3_kernel(const DwArgs a, const int TYL, const int dbg) {
   constexpr int NT = 8 * TX;
   constexpr int VEC = Elem<T>::VEC;
   constexpr int CC = 8 * VEC;  // channels per workgroup
@@ -95,7 +95,7 @@ __global__ void __launch_bounds__(8 * TX) dwconv3x3_kernel(const DwArgs a, const
       const int gy = y0 - 1 + r;
       const bool row_ok = gy >= 0 && gy < a.H;
       vec_t* buf = ring[j & 1];  // PF is even, so r & 1 == j & 1
-      buf[(xl + 1) * 8 + cl] = row_ok ? activate(pre[j]) : zero;
+      buf[(xl + 1) * 8 + cl] = row_ok ? ((dbg & 2) ? pre[j] : activate(pre[j])) : zero;
       if (is_halo) buf[hslot * 8 + cl] = (row_ok && hx_ok) ? activate(preh[j]) : zero;
       issue(r + PF, pre[j], preh[j]);
       __syncthreads();
@@ -111,6 +111,10 @@ __global__ void __launch_bounds__(8 * TX) dwconv3x3_kernel(const DwArgs a, const
           asm volatile("" : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]));
         }
       }
+      if (dbg & 1) {  // ablation: no multiply-accumulate (timing experiments only)
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) acc0[e] += (float)f[1][e];
+      } else {
 #pragma unroll
       for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
@@ -119,6 +123,7 @@ __global__ void __launch_bounds__(8 * TX) dwconv3x3_kernel(const DwArgs a, const
           acc1[e] += (float)w[3 + kx][e] * (float)f[kx][e];  // ky = 1 -> output row r-1
           acc2[e] += (float)w[0 + kx][e] * (float)f[kx][e];  // ky = 0 -> output row r
         }
+      }
       if (r >= 2) {
         vec_t ov = f32_to_vec<T>(acc0);
         st_vec<T>(out + ((size_t)(y0 + r - 2) * a.W + x0 + xl) * a.C, ov);
@@ -155,6 +160,8 @@ __global__ void __launch_bounds__(8 * TX) dwconv3x3_kernel(const DwArgs a, const
   }
 }
 
+static int g_dw_dbg = 0;
+void dwconv_debug(int v) { g_dw_dbg = v; }
 static int dw_tx(int W) { return (W % 32 == 0) ? 32 : ((W % 16 == 0) ? 16 : 8); }
 static int dw_tyl(int H) { return (H % 32 == 0) ? 32 : ((H % 16 == 0) ? 16 : 8); }
 int dwconv_ntiles(int H, int W) { return (H / dw_tyl(H)) * (W / dw_tx(W)); }
@@ -165,9 +172,9 @@ static hipError_t launch_dw_t(const DwArgs& a, hipStream_t s) {
   if (a.C % CC || a.H % 8 || a.W % 8) return hipErrorInvalidValue;
   const int tx = dw_tx(a.W), tyl = dw_tyl(a.H);
   dim3 grid((a.W / tx) * (a.H / tyl), a.C / CC, a.B);
-  if (tx == 32) hipLaunchKernelGGL((dwconv3x3_kernel<T, 32>), grid, dim3(256), 0, s, a, tyl);
-  else if (tx == 16) hipLaunchKernelGGL((dwconv3x3_kernel<T, 16>), grid, dim3(128), 0, s, a, tyl);
-  else hipLaunchKernelGGL((dwconv3x3_kernel<T, 8>), grid, dim3(64), 0, s, a, tyl);
+  if (tx == 32) hipLaunchKernelGGL((dwconv3x3_kernel<T, 32>), grid, dim3(256), 0, s, a, tyl, g_dw_dbg);
+  else if (tx == 16) hipLaunchKernelGGL((dwconv3x3_kernel<T, 16>), grid, dim3(128), 0, s, a, tyl, g_dw_dbg);
+  else hipLaunchKernelGGL((dwconv3x3_kernel<T, 8>), grid, dim3(64), 0, s, a, tyl, g_dw_dbg);
   return hipGetLastError();
 }
 

@@ -139,6 +139,7 @@ struct llie_ctx {
   // UNet-level tensors
   size_t t_w1 = 0, t_b1 = 0, t_w3 = 0, t_b3 = 0, freqs = 0, film_w = 0, film_b = 0;
   int film_rows = 0;
+  size_t init_wp = 0;  // MFMA-packed init_conv weights (2-byte compute dtypes)
   size_t init_w = 0, init_b = 0, fin_g = 0, fin_b = 0, fin_w = 0, fin_bias = 0;
   // hipGraph cache of llie_enhance launch sequences (key -> executable graph)
   struct GraphEntry { bool seen = false; hipGraphExec_t exec = nullptr; hipGraph_t graph = nullptr; };
@@ -309,6 +310,7 @@ int build_unet(llie_ctx* c) {
   c->init_w = b.reserve((size_t)ch[0] * g.in_channels * 9 * 4);
   { Param& p = b.add("init_conv.weight", (int64_t)ch[0] * g.in_channels * 9, PK_INIT, c->init_w); p.O = ch[0]; p.I = g.in_channels; Builder::set_shape(p, {ch[0], g.in_channels, 3, 3}); }
   c->init_b = b.f32("init_conv.bias", ch[0]);
+  c->init_wp = b.reserve((size_t)10 * ch[0] * 8 * 2);
 
   int res = g.image_size;
   auto is_attn_res = [&](int r) { return r == g.attention_resolutions[0] || r == g.attention_resolutions[1]; };
@@ -620,6 +622,7 @@ struct Run {
       const int half = g.in_channels / 2;
       a.x0 = lat; a.x1 = cond; a.c0 = half; a.c1 = g.in_channels - half;
       a.w = wptr<float>(c->init_w); a.bias = wptr<float>(c->init_b); a.out = p(h.off); a.stats = p<float>(h.slab);
+      a.wp = dt != LLIE_F32 ? wptr(c->init_wp) : nullptr;
       a.B = B; a.H = S; a.W = S; a.Cout = c->channels[0];
       chk(launch_init_conv(dt, a, s));
     }
@@ -818,7 +821,10 @@ int llie_load_param(llie_ctx* c, const char* key, const float* src, int64_t nume
     case PK_MAT: e = launch_cvt_rows(p.as_t ? c->dt : 0, src, dst, p.rows, p.cols, p.ld, p.col0, s); break;
     case PK_CONV3: e = launch_repack_conv3x3(c->dt, src, dst, p.O, p.I, s); break;
     case PK_DW: e = launch_repack_dw(src, reinterpret_cast<float*>(dst), p.O, s); break;
-    case PK_INIT: e = launch_repack_init(src, reinterpret_cast<float*>(dst), p.O, p.I, s); break;
+    case PK_INIT:
+      e = launch_repack_init(src, reinterpret_cast<float*>(dst), p.O, p.I, s);
+      if (e == hipSuccess && c->dt != LLIE_F32) e = launch_repack_init_mfma(c->dt, src, c->blob + c->init_wp, p.O, p.I, s);
+      break;
     case PK_FINAL: e = launch_repack_final(src, reinterpret_cast<float*>(dst), p.O, p.I, s); break;
   }
   if (e != hipSuccess) { set_err("repack of '%s' failed: %s", key, hipGetErrorString(e)); return (int)e; }
@@ -1051,6 +1057,8 @@ int llie_pw_gemm_tile_rows(int P) { return pw_gemm_tile_rows(P); }
 int llie_tune(const char* knob, int value) {
   if (!knob) return LLIE_ERR_ARG;
   if (!strcmp(knob, "gemm_bk")) { pw_gemm_force_bk(value); return LLIE_OK; }
+  if (!strcmp(knob, "gemm_ablate")) { pw_gemm_debug(value); return LLIE_OK; }
+  if (!strcmp(knob, "dw_ablate")) { dwconv_debug(value); return LLIE_OK; }
   return LLIE_ERR_ARG;
 }
 

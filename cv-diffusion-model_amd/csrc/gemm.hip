@@ -127,9 +127,9 @@ __global__ void __launch_bounds__(WM* WN * 64) pw_gemm_kernel(const GemmArgs g) 
   const int nchunks = g.K / BK;
   prefetch(0);
   for (int c = 0; c < nchunks; ++c) {
-    stage();
+    if (!(g.dbg & 2) || c == 0) stage();  // dbg bit 1: timing ablation (no re-staging)
     __syncthreads();
-    if (c + 1 < nchunks) prefetch((c + 1) * BK);
+    if (c + 1 < nchunks && !(g.dbg & 1)) prefetch((c + 1) * BK);  // dbg bit 0: timing ablation (stale tiles)
     const int lr = lane & 31, lk = (lane >> 5) * 16;
 #pragma unroll
     for (int sub = 0; sub < BK / 32; ++sub) {
@@ -281,7 +281,12 @@ static hipError_t launch_t(const GemmArgs& a, hipStream_t s) {
   return launch_cfg<T, 64, 32, 2, 1, 32>(a, s);
 }
 
-hipError_t launch_pw_gemm(int dtype, const GemmArgs& a, hipStream_t s) {
+static int g_gemm_dbg = 0;
+void pw_gemm_debug(int v) { g_gemm_dbg = v; }
+
+hipError_t launch_pw_gemm(int dtype, const GemmArgs& a0, hipStream_t s) {
+  GemmArgs a = a0;
+  a.dbg = g_gemm_dbg;
   // host-side shape contract of the kernel (checked before any launch: an out-of-contract shape
   // would index out of bounds on the device)
   if (a.nseg < 1 || a.nseg > 3 || a.N % 32 || a.K % 32 || a.P % 64 || a.M % a.P) return hipErrorInvalidValue;

@@ -40,10 +40,12 @@ struct GemmArgs {
   float* stats;       // slab of out or null
   int M, N, K;        // K = sum of seg ch
   int P;              // rows (pixels) per image; M = B * P
+  int dbg;            // timing ablations (set by the launcher from pw_gemm_debug; 0 in production)
 };
 hipError_t launch_pw_gemm(int dtype, const GemmArgs& a, hipStream_t s);
 int pw_gemm_tile_rows(int P);  // BM used for a given P (stats slab tiles = P / BM)
 void pw_gemm_force_bk(int bk);  // tuning knob (0 = automatic)
+void pw_gemm_debug(int v);      // timing ablations; results are wrong when non-zero
 
 // GroupNorm statistics -> per-(image, channel) affine tables.
 //   mean/var over groups of cg = C/32 channels x P pixels from up to two slabs (virtual concat),
@@ -76,6 +78,7 @@ struct DwArgs {
 };
 hipError_t launch_dwconv3x3(int dtype, const DwArgs& a, hipStream_t s);
 int dwconv_ntiles(int H, int W);
+void dwconv_debug(int v);  // timing ablations (bit 0: no MACs, bit 1: no activation); results are wrong when set
 
 // Squeeze-and-Excitation MLP (efficient_unet.py:96-100) in two launches.
 //   fc1: mean[b][c] = sum_tiles pool / P (own launch);  hid[b][j] = relu6(b1[j] + sum_c W1[j][c] * mean[b][c])
@@ -119,6 +122,7 @@ hipError_t launch_silu_rows(const float* in, float* out, int64_t n, hipStream_t 
 struct InitConvArgs {
   const float* x0; const float* x1; int c0, c1;  // c0 + c1 = Cin
   const float* w; const float* bias;             // [Cin*9][Cout] (repacked), [Cout] fp32
+  const void* wp;                                // 2-byte T only: MFMA-packed [5][2][Cout][8] T, or null (VALU kernel)
   void* out; float* stats;
   int B, H, W, Cout;
 };
@@ -175,6 +179,7 @@ hipError_t launch_repack_conv3x3(int dtype, const float* src, void* dst, int Cou
 hipError_t launch_repack_dw(const float* src, float* dst, int C, hipStream_t s);                             // [C][1][3][3] -> [9][C]
 hipError_t launch_repack_init(const float* src, float* dst, int O, int I, hipStream_t s);                    // OIHW -> [I*9][O]
 hipError_t launch_repack_final(const float* src, float* dst, int O, int I, hipStream_t s);                   // OIHW -> [9][I][4]
+hipError_t launch_repack_init_mfma(int dtype, const float* src, void* dst, int O, int I, hipStream_t s);     // OIHW -> [5][2][O][8] T
 
 // LCM scheduler elementwise ops (fp32).
 struct StepCoef { float sa, sb, sap, sbp; int is_last; int vpred; };

@@ -566,6 +566,24 @@ hipError_t launch_repack_init(const float* src, float* dst, int O, int I, hipStr
   hipLaunchKernelGGL(repack_init_kernel, dim3((O * I * 9 + 255) / 256), dim3(256), 0, s, src, dst, O, I);
   return hipGetLastError();
 }
+// init_conv for the MFMA kernel: dst[((s*2+h)*O + n)*8 + ci] = W[n][ci][tap = 2s+h] (zero when tap > 8 or ci >= I)
+template <typename T>
+__global__ void repack_init_mfma_kernel(const float* src, T* dst, int O, int I) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 10 * O * 8) return;
+  const int ci = i & 7, n = (i >> 3) % O, tap = (i >> 3) / O;
+  dst[i] = (tap < 9 && ci < I) ? (T)src[((size_t)n * I + ci) * 9 + tap] : (T)0.f;
+}
+hipError_t launch_repack_init_mfma(int dtype, const float* src, void* dst, int O, int I, hipStream_t s) {
+  if (I > 8) return hipErrorInvalidValue;
+  dim3 grid((10 * O * 8 + 255) / 256);
+  switch (dtype) {
+    case 1: hipLaunchKernelGGL(repack_init_mfma_kernel<half_t>, grid, dim3(256), 0, s, src, (half_t*)dst, O, I); break;
+    case 2: hipLaunchKernelGGL(repack_init_mfma_kernel<bf16_t>, grid, dim3(256), 0, s, src, (bf16_t*)dst, O, I); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
 __global__ void repack_final_kernel(const float* src, float* dst, int O, int I) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= 9 * I * 4) return;

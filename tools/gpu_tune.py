@@ -90,19 +90,27 @@ SHAPES = [  # (name, kind, P, segs, N)   small@256, B=32
 
 if __name__ == "__main__":
     B = 32
-    knobs = [("auto", 0), ("bk32", 32)]
-    print(f"{'shape':28s} " + " ".join(f"{k:>26s}" for k, _ in knobs))
-    tot = {k: 0.0 for k, _ in knobs}
-    for name, kind, P, segs, n in SHAPES:
-        row = []
-        for k, v in knobs:
-            L.llie_tune(b"gemm_bk", v)
-            us, gbs, tf = gemm(kind, B * P, segs, n, P)
-            tot[k] += us
-            row.append(f"{us:8.1f}us {gbs:6.0f}GB/s {tf:5.0f}TF")
-        print(f"{name:28s} " + " ".join(f"{r:>26s}" for r in row), flush=True)
-    print("sum(us):", {k: round(v, 1) for k, v in tot.items()})
-    L.llie_tune(b"gemm_bk", 0)
-    for H, Cc in [(256, 128), (256, 384), (128, 256), (128, 768), (64, 512), (64, 1536), (32, 1024), (32, 2048)]:
-        us, gbs = dw(B, H, Cc)
-        print(f"dw {H}x{H} C={Cc}: {us:8.1f} us  {gbs:6.0f} GB/s", flush=True)
+    if "gemm" in sys.argv[1:]:
+        knobs = [("normal", 0), ("noloads", 1), ("nostage", 3), ("normal2", 0)]
+        print(f"{'shape':28s} " + " ".join(f"{k:>16s}" for k, _ in knobs))
+        tot = {k: 0.0 for k, _ in knobs}
+        for name, kind, P, segs, n in SHAPES:
+            row = []
+            for k, v in knobs:
+                L.llie_tune(b"gemm_ablate", v)
+                us, gbs, tf = gemm(kind, B * P, segs, n, P)
+                tot[k] += us
+                row.append(f"{us:8.1f}us {tf:5.0f}TF")
+            print(f"{name:28s} " + " ".join(f"{r:>16s}" for r in row), flush=True)
+        print("sum(us):", {k: round(v, 1) for k, v in tot.items()})
+        L.llie_tune(b"gemm_ablate", 0)
+    if "dw" in sys.argv[1:]:
+        for rep in range(2):
+            for H, Cc in [(256, 128), (256, 384), (128, 768), (64, 1536)]:
+                row = []
+                for mode in (0, 1, 2, 3):
+                    L.llie_tune(b"dw_ablate", mode)
+                    us, gbs = dw(B, H, Cc)
+                    row.append(f"m{mode}: {us:7.1f}us {gbs:5.0f}GB/s")
+                print(f"dw {H}x{H} C={Cc}: " + " | ".join(row), flush=True)
+        L.llie_tune(b"dw_ablate", 0)
