@@ -258,13 +258,115 @@ __global__ void __launch_bounds__(256) final_conv_kernel(const FinalConvArgs a) 
   for (int o = 0; o < 4; ++o)
     if (o < a.Cout) a.out[(((size_t)b * a.Cout + o) * a.H + y0 + py) * a.W + x0 + px] = acc[o] + a.bias[o];
 }
+// ---------------------------------------------------------------------------------------------
+// final head on MFMA (2-byte T) with the LCM scheduler step fused into the epilogue.
+// Roles are swapped relative to a usual conv-GEMM: the (zero-padded) weights are the A operand
+// (rows = output channel, only rows 0..2 are non-zero) and the activated halo patch is the B operand
+// (columns = pixels), so after the K loop lane p of lane-half 0 holds the 3 outputs of ITS pixel in
+// acc[0..2]: the epilogue (bias, LCMScheduler.step lcm_scheduler.py:204-242, clamp
+// low_light_diffusion.py:240) is per-lane and its fp32 NCHW accesses are 64-byte row segments.
+// K order per 32-channel chunk: k-step = (tap, 16-channel half); lane half h takes 8 channels.
+// Weights pre-packed as [chunk][18][2][4][8] T (output channel padded to 4).
+template <typename T>
+__global__ void __launch_bounds__(256) final_conv_mfma_kernel(const FinalConvArgs a) {
+  typedef typename Elem<T>::vec_t vec_t;
+  constexpr int PWD = 19, PIX = 40;  // pixel pitch 80 B: conflict-free ds_read_b128 (cf. TilePitch)
+  __shared__ __align__(16) T patch[(18 * PWD + 1) * PIX];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tiles_x = a.W / 16;
+  const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x, b = blockIdx.y;
+  const int x0 = tx * 16, y0 = ty * 16;
+  const T* in = reinterpret_cast<const T*>(a.in) + (size_t)b * a.H * a.W * a.C;
+  const T* wp = reinterpret_cast<const T*>(a.wp);
+  const int r = lane & 31, h = lane >> 5;
+  f32x16 acc[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[t][q] = 0.f;
+  vec_t zero;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) zero[e] = (T)0.f;
+
+  for (int cc = 0; cc < a.C; cc += 32) {
+    if (cc) __syncthreads();
+    // stage the activated 18x18x32 patch (GroupNorm affine + SiLU applied once per element)
+    for (int i = tid; i < (18 * PWD + 1) * 4; i += 256) {
+      const int pix = i >> 2, cv = (i & 3) * 8;
+      const int ppy = pix / PWD, ppx = pix % PWD;
+      const int gy = y0 + ppy - 1, gx = x0 + ppx - 1;
+      vec_t v = zero;
+      if (pix < 18 * PWD && ppx < 18 && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {
+        float f[8];
+        ld_f32<T>(in + ((size_t)gy * a.W + gx) * a.C + cc + cv, f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int c = cc + cv + e;
+          f[e] = siluf(f[e] * a.as[(size_t)b * a.C + c] + a.ab[(size_t)b * a.C + c]);
+        }
+        v = f32_to_vec<T>(f);
+      }
+      *reinterpret_cast<vec_t*>(patch + pix * PIX + cv) = v;
+    }
+    __syncthreads();
+    // A operand: this lane's weight fragments (non-zero only for output channels r < 4)
+    vec_t wf[18];
+#pragma unroll
+    for (int ks = 0; ks < 18; ++ks)
+      wf[ks] = r < 4 ? ld_vec<T>(wp + ((((size_t)(cc >> 5) * 18 + ks) * 2 + h) * 4 + r) * 8) : zero;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int g = wave * 2 + t;
+      const int py = 2 * g + (r >> 4), px = r & 15;
+#pragma unroll
+      for (int ks = 0; ks < 18; ++ks) {
+        const int tap = ks >> 1, q = ks & 1;
+        const vec_t bv = *reinterpret_cast<const vec_t*>(patch + ((py + tap / 3) * PWD + px + tap % 3) * PIX + q * 16 + h * 8);
+        if constexpr (std::is_same<T, half_t>::value) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[ks], bv, acc[t], 0, 0, 0);
+        else acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks], bv, acc[t], 0, 0, 0);
+      }
+    }
+  }
+  if (h) return;  // rows 4..7 of D (lane half 1) are padding
+  const size_t plane = (size_t)a.H * a.W;
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int g = wave * 2 + t;
+    const int y = y0 + 2 * g + (r >> 4), x = x0 + (r & 15);
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+      if (o >= a.Cout) break;
+      const size_t idx = ((size_t)b * a.Cout + o) * plane + (size_t)y * a.W + x;
+      const float e = acc[t][o] + a.bias[o];
+      if (a.out) a.out[idx] = e;
+      if (a.fuse_step) {
+        const float xv = a.sample[idx];
+        float x0v;
+        if (a.coef.vpred) x0v = __fsub_rn(__fmul_rn(a.coef.sa, xv), __fmul_rn(a.coef.sb, e));
+        else x0v = __fdiv_rn(__fsub_rn(xv, __fmul_rn(a.coef.sb, e)), a.coef.sa);
+        float pv = x0v;
+        if (!a.coef.is_last) pv = __fadd_rn(__fmul_rn(a.coef.sap, x0v), __fmul_rn(a.coef.sbp, a.noise[idx]));
+        a.prev[idx] = pv;
+        if (a.clamped) a.clamped[idx] = fminf(fmaxf(pv, -1.f), 1.f);
+      }
+    }
+  }
+}
 hipError_t launch_final_conv(int dtype, const FinalConvArgs& a, hipStream_t s) {
   if (a.H % 16 || a.W % 16 || a.C % 32 || a.Cout > 4) return hipErrorInvalidValue;
+  if (a.fuse_step && (!a.wp || dtype == 0 || !a.sample || !a.prev || (!a.coef.is_last && !a.noise))) return hipErrorInvalidValue;
+  if (!a.fuse_step && !a.out) return hipErrorInvalidValue;
   dim3 grid((a.H / 16) * (a.W / 16), a.B);
   switch (dtype) {
     case 0: hipLaunchKernelGGL(final_conv_kernel<float>, grid, dim3(256), 0, s, a); break;
-    case 1: hipLaunchKernelGGL(final_conv_kernel<half_t>, grid, dim3(256), 0, s, a); break;
-    case 2: hipLaunchKernelGGL(final_conv_kernel<bf16_t>, grid, dim3(256), 0, s, a); break;
+    case 1:
+      if (a.wp) hipLaunchKernelGGL(final_conv_mfma_kernel<half_t>, grid, dim3(256), 0, s, a);
+      else hipLaunchKernelGGL(final_conv_kernel<half_t>, grid, dim3(256), 0, s, a);
+      break;
+    case 2:
+      if (a.wp) hipLaunchKernelGGL(final_conv_mfma_kernel<bf16_t>, grid, dim3(256), 0, s, a);
+      else hipLaunchKernelGGL(final_conv_kernel<bf16_t>, grid, dim3(256), 0, s, a);
+      break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();

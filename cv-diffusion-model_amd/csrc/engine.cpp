@@ -139,7 +139,7 @@ struct llie_ctx {
   // UNet-level tensors
   size_t t_w1 = 0, t_b1 = 0, t_w3 = 0, t_b3 = 0, freqs = 0, film_w = 0, film_b = 0;
   int film_rows = 0;
-  size_t init_wp = 0;  // MFMA-packed init_conv weights (2-byte compute dtypes)
+  size_t init_wp = 0, fin_wp = 0;  // MFMA-packed init / final conv weights (2-byte compute dtypes)
   size_t init_w = 0, init_b = 0, fin_g = 0, fin_b = 0, fin_w = 0, fin_bias = 0;
   // hipGraph cache of llie_enhance launch sequences (key -> executable graph)
   struct GraphEntry { bool seen = false; hipGraphExec_t exec = nullptr; hipGraph_t graph = nullptr; };
@@ -354,6 +354,7 @@ int build_unet(llie_ctx* c) {
   c->fin_w = b.reserve((size_t)9 * ch[0] * 4 * 4);
   { Param& p = b.add("final_conv.weight", (int64_t)g.out_channels * ch[0] * 9, PK_FINAL, c->fin_w); p.O = g.out_channels; p.I = ch[0]; Builder::set_shape(p, {g.out_channels, ch[0], 3, 3}); }
   c->fin_bias = b.f32("final_conv.bias", g.out_channels);
+  c->fin_wp = b.reserve((size_t)(ch[0] / 32) * 18 * 2 * 4 * 8 * 2);
   c->freqs = b.reserve((size_t)(g.base_channels / 2) * 4);
   b.finish_film();
   c->blob_bytes = b.cursor;
@@ -596,7 +597,9 @@ struct Run {
   }
 
   // EfficientUNet.forward (efficient_unet.py:532-606)
-  void unet(const float* lat, const float* cond, const int64_t* t, int uniform_t, float* eps) {
+  // `fs` (optional): scheduler step fused into the final conv's epilogue (2-byte compute dtypes only)
+  struct FusedStep { StepCoef coef; const float* noise; float* prev; float* clamped; };
+  void unet(const float* lat, const float* cond, const int64_t* t, int uniform_t, float* eps, const FusedStep* fs = nullptr) {
     const llie_config& g = c->cfg;
     const int S = g.image_size, T = g.time_embed_dim, F = c->film_rows;
     const int rows = uniform_t ? 1 : B;
@@ -650,6 +653,10 @@ struct Run {
       FinalConvArgs a{};
       a.in = p(h.off); a.as = p<float>(as); a.ab = p<float>(ab); a.w = wptr<float>(c->fin_w); a.bias = wptr<float>(c->fin_bias);
       a.out = eps; a.B = B; a.H = S; a.W = S; a.C = c->channels[0]; a.Cout = g.out_channels;
+      a.wp = dt != LLIE_F32 ? wptr(c->fin_wp) : nullptr;
+      if (fs) {
+        a.fuse_step = 1; a.coef = fs->coef; a.sample = lat; a.noise = fs->noise; a.prev = fs->prev; a.clamped = fs->clamped;
+      }
       chk(launch_final_conv(dt, a, s));
     }
     free_tens(h);
@@ -825,7 +832,10 @@ int llie_load_param(llie_ctx* c, const char* key, const float* src, int64_t nume
       e = launch_repack_init(src, reinterpret_cast<float*>(dst), p.O, p.I, s);
       if (e == hipSuccess && c->dt != LLIE_F32) e = launch_repack_init_mfma(c->dt, src, c->blob + c->init_wp, p.O, p.I, s);
       break;
-    case PK_FINAL: e = launch_repack_final(src, reinterpret_cast<float*>(dst), p.O, p.I, s); break;
+    case PK_FINAL:
+      e = launch_repack_final(src, reinterpret_cast<float*>(dst), p.O, p.I, s);
+      if (e == hipSuccess && c->dt != LLIE_F32) e = launch_repack_final_mfma(c->dt, src, c->blob + c->fin_wp, p.O, p.I, s);
+      break;
   }
   if (e != hipSuccess) { set_err("repack of '%s' failed: %s", key, hipGetErrorString(e)); return (int)e; }
   p.loaded = true;
@@ -864,9 +874,18 @@ int64_t llie_enhance_workspace_bytes(llie_ctx* c, int batch, int max_steps) {
   return core + (int64_t)((2 + 3 * (size_t)max_steps) * img + align_up((size_t)max_steps * batch * 8, 256));
 }
 
+static int unet_forward_impl(llie_ctx* c, const float* lat, const float* cond, const int64_t* t, int uniform_t, float* eps,
+                             const Run::FusedStep* fs, int batch, void* ws, int64_t ws_bytes, llie_stream stream);
+
 int llie_unet_forward(llie_ctx* c, const float* lat, const float* cond, const int64_t* t, int uniform_t, float* eps,
                       int batch, void* ws, int64_t ws_bytes, llie_stream stream) {
-  if (!c || !lat || !cond || !t || !eps || !ws || batch <= 0 || c->cfg.kind != LLIE_UNET) return LLIE_ERR_ARG;
+  if (!eps) return LLIE_ERR_ARG;
+  return unet_forward_impl(c, lat, cond, t, uniform_t, eps, nullptr, batch, ws, ws_bytes, stream);
+}
+
+static int unet_forward_impl(llie_ctx* c, const float* lat, const float* cond, const int64_t* t, int uniform_t, float* eps,
+                             const Run::FusedStep* fs, int batch, void* ws, int64_t ws_bytes, llie_stream stream) {
+  if (!c || !lat || !cond || !t || (!eps && !fs) || !ws || batch <= 0 || c->cfg.kind != LLIE_UNET) return LLIE_ERR_ARG;
   if (!c->blob) { set_err("no HIP device"); return LLIE_ERR_NO_DEVICE; }
   int rc = check_loaded(c);
   if (rc) return rc;
@@ -878,7 +897,7 @@ int llie_unet_forward(llie_ctx* c, const float* lat, const float* cond, const in
     d.unet(nullptr, nullptr, nullptr, uniform_t, nullptr);
     if ((int64_t)probe.high > ws_bytes) { set_err("workspace too small: need %zu, have %lld", probe.high, (long long)ws_bytes); return LLIE_ERR_WORKSPACE; }
   }
-  r.unet(lat, cond, t, uniform_t, eps);
+  r.unet(lat, cond, t, uniform_t, eps, fs);
   return finish_run(r, ws_bytes);
 }
 
@@ -935,15 +954,27 @@ static int enhance_sequence(llie_ctx* c, const float* low, const float* noise, c
   void* uws = base + 3 * img;
   const int64_t uws_bytes = ws_bytes - (int64_t)(3 * img);
   const float* cur = noise;  // initial latents = first draw (low_light_diffusion.py:208-211)
+  const bool fuse = c->dt != LLIE_F32;  // the MFMA output head applies the scheduler step in its epilogue
   for (int i = 0; i < steps; ++i) {
-    float* eps = preds ? preds + (size_t)i * n : eps_ws;
-    int rc = llie_unet_forward(c, cur, low, t_dev + (size_t)i * batch, 1, eps, batch, uws, uws_bytes, stream);
-    if (rc) return rc;
     const bool last = i == steps - 1;
     float* prev = inter ? inter + (size_t)i * n : lat[i & 1];
-    rc = llie_lcm_step(eps, cur, coefs[i].is_last ? nullptr : noise + (size_t)(i + 1) * n, prev, nullptr,
-                       last ? enhanced : nullptr, n, &coefs[i], stream);
-    if (rc) return rc;
+    const float* nz = coefs[i].is_last ? nullptr : noise + (size_t)(i + 1) * n;
+    if (!coefs[i].is_last && i + 1 >= steps) return LLIE_ERR_ARG;  // a non-final step needs a noise draw
+    int rc;
+    if (fuse) {
+      Run::FusedStep fs{StepCoef{coefs[i].sqrt_alpha_t, coefs[i].sqrt_beta_t, coefs[i].sqrt_alpha_prev, coefs[i].sqrt_beta_prev,
+                                 coefs[i].is_last, coefs[i].v_prediction},
+                        nz, prev, last ? enhanced : nullptr};
+      rc = unet_forward_impl(c, cur, low, t_dev + (size_t)i * batch, 1, preds ? preds + (size_t)i * n : nullptr, &fs, batch,
+                             uws, uws_bytes, stream);
+      if (rc) return rc;
+    } else {
+      float* eps = preds ? preds + (size_t)i * n : eps_ws;
+      rc = llie_unet_forward(c, cur, low, t_dev + (size_t)i * batch, 1, eps, batch, uws, uws_bytes, stream);
+      if (rc) return rc;
+      rc = llie_lcm_step(eps, cur, nz, prev, nullptr, last ? enhanced : nullptr, n, &coefs[i], stream);
+      if (rc) return rc;
+    }
     cur = prev;
   }
   return LLIE_OK;

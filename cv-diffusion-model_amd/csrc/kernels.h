@@ -128,12 +128,18 @@ struct InitConvArgs {
 };
 hipError_t launch_init_conv(int dtype, const InitConvArgs& a, hipStream_t s);
 int init_conv_ntiles(int H, int W);
-//   final: NHWC T -> affine + SiLU -> 3x3 conv C->Cout(3) -> fp32 NCHW
+//   final: NHWC T -> affine + SiLU -> 3x3 conv C->Cout(3) -> fp32 NCHW; the MFMA variant (2-byte T)
+//   can apply LCMScheduler.step to its own output in the epilogue (fuse_step).
+struct StepCoef { float sa, sb, sap, sbp; int is_last; int vpred; };
 struct FinalConvArgs {
   const void* in; const float* as; const float* ab;
   const float* w; const float* bias;             // [9][C][4] (repacked, zero padded), [Cout]
-  float* out;
+  const void* wp;                                // 2-byte T only: MFMA-packed [C/32][18][2][4][8] T, or null (VALU kernel)
+  float* out;                                    // noise prediction (may be null when fuse_step)
   int B, H, W, C, Cout;
+  int fuse_step;                                 // 1: also prev = step(eps, sample, noise) (and clamp)
+  StepCoef coef;
+  const float* sample; const float* noise; float* prev; float* clamped;
 };
 hipError_t launch_final_conv(int dtype, const FinalConvArgs& a, hipStream_t s);
 //   implicit-GEMM MFMA conv: mode 0 = stride-2 downsample, 1 = bilinear x2 upsample then conv (pad 1).
@@ -179,10 +185,10 @@ hipError_t launch_repack_conv3x3(int dtype, const float* src, void* dst, int Cou
 hipError_t launch_repack_dw(const float* src, float* dst, int C, hipStream_t s);                             // [C][1][3][3] -> [9][C]
 hipError_t launch_repack_init(const float* src, float* dst, int O, int I, hipStream_t s);                    // OIHW -> [I*9][O]
 hipError_t launch_repack_final(const float* src, float* dst, int O, int I, hipStream_t s);                   // OIHW -> [9][I][4]
+hipError_t launch_repack_final_mfma(int dtype, const float* src, void* dst, int O, int I, hipStream_t s);    // OIHW -> [I/32][18][2][4][8] T
 hipError_t launch_repack_init_mfma(int dtype, const float* src, void* dst, int O, int I, hipStream_t s);     // OIHW -> [5][2][O][8] T
 
 // LCM scheduler elementwise ops (fp32).
-struct StepCoef { float sa, sb, sap, sbp; int is_last; int vpred; };
 hipError_t launch_lcm_step(const float* eps, const float* x, const float* noise, float* prev, float* x0,
                            float* clamped, int64_t n, StepCoef c, hipStream_t s);
 hipError_t launch_add_noise(const float* x0, const float* noise, const int64_t* t, const float* acp, float* out,

@@ -81,24 +81,59 @@ hipError_t launch_gn_finalize(const GnFinalizeArgs& a, hipStream_t s) {
 // weight row is read once per launch.
 constexpr int kSeMaxB = 4;  // images per pass held in registers / LDS
 
-// pool partials [B][ntiles][C] -> mean[B][C]: one block per (64 channels, image); wave w takes tiles
-// w, w+4, ... and the four partial sums are combined in a fixed order.
+// pool partials [B][ntiles][C] -> mean[B][C]: one block per (64 channels, image).  Thread t owns a
+// float4 of channels (t & 15) and a tile group (t >> 4): 16 groups stride over the tiles with 16-byte
+// loads; the 16 partial sums per channel are combined through LDS in a fixed order.
 __global__ void __launch_bounds__(256) se_pool_kernel(const SeArgs a) {
-  __shared__ float part[4][64];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int c = blockIdx.x * 64 + lane, b = blockIdx.y;
-  float s = 0.f;
+  __shared__ float part[16][64];
+  const int tid = threadIdx.x, c4 = tid & 15, tg = tid >> 4;
+  const int c = blockIdx.x * 64 + c4 * 4, b = blockIdx.y;
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
   if (c < a.C) {
     const float* p = a.pool + (size_t)b * a.ntiles * a.C + c;
-    for (int t = wave; t < a.ntiles; t += 4) s += p[(size_t)t * a.C];
+    for (int t = tg; t < a.ntiles; t += 16) s += *reinterpret_cast<const f32x4*>(p + (size_t)t * a.C);
   }
-  part[wave][lane] = s;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) part[tg][c4 * 4 + e] = s[e];
   __syncthreads();
-  if (wave == 0 && c < a.C)
-    a.mean[(size_t)b * a.C + c] = (part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane]) * (1.f / (float)a.P);
+  if (tid < 64 && blockIdx.x * 64 + tid < a.C) {
+    float t = 0.f;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) t += part[g][tid];
+    a.mean[(size_t)b * a.C + blockIdx.x * 64 + tid] = t * (1.f / (float)a.P);
+  }
 }
 
 constexpr int kSeRows = 8;  // output rows per block (2 per wave)
+
+// dot products of one weight row (K contiguous T elements, 16-byte vector loads) with kSeMaxB fp32
+// vectors held in LDS; wave-wide, every lane gets the totals.
+template <typename T>
+__device__ __forceinline__ void se_row_dots(const T* wrow, const float* vecs, int K, int nb, int lane, float* out) {
+  constexpr int VEC = Elem<T>::VEC;
+  float acc[kSeMaxB];
+#pragma unroll
+  for (int q = 0; q < kSeMaxB; ++q) acc[q] = 0.f;
+  const int kvec = K / VEC * VEC;
+  for (int k = lane * VEC; k < kvec; k += 64 * VEC) {
+    float w[VEC];
+    ld_f32<T>(wrow + k, w);
+#pragma unroll
+    for (int q = 0; q < kSeMaxB; ++q)
+      if (q < nb) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) acc[q] += w[e] * vecs[q * K + k + e];
+      }
+  }
+  for (int k = kvec + lane; k < K; k += 64) {  // tail (K not a multiple of the vector width)
+    const float w = (float)wrow[k];
+#pragma unroll
+    for (int q = 0; q < kSeMaxB; ++q)
+      if (q < nb) acc[q] += w * vecs[q * K + k];
+  }
+#pragma unroll
+  for (int q = 0; q < kSeMaxB; ++q) out[q] = wave_sum(acc[q]);
+}
 
 template <typename T>
 __global__ void __launch_bounds__(256) se_fc1_kernel(const SeArgs a) {
@@ -111,20 +146,11 @@ __global__ void __launch_bounds__(256) se_fc1_kernel(const SeArgs a) {
   for (int jj = wave; jj < kSeRows; jj += 4) {
     const int j = blockIdx.x * kSeRows + jj;
     if (j >= a.Cs) break;
-    float acc[kSeMaxB];
+    float v[kSeMaxB];
+    se_row_dots<T>(w1 + (size_t)j * a.C, smean, a.C, nb, lane, v);
 #pragma unroll
-    for (int q = 0; q < kSeMaxB; ++q) acc[q] = 0.f;
-    for (int c = lane; c < a.C; c += 64) {
-      const float w = (float)w1[(size_t)j * a.C + c];
-#pragma unroll
-      for (int q = 0; q < kSeMaxB; ++q)
-        if (q < nb) acc[q] += w * smean[q * a.C + c];
-    }
-#pragma unroll
-    for (int q = 0; q < kSeMaxB; ++q) {
-      const float v = wave_sum(acc[q]);
-      if (q < nb && lane == 0) a.hid[(size_t)(b0 + q) * a.Cs + j] = relu6f(v + a.b1[j]);
-    }
+    for (int q = 0; q < kSeMaxB; ++q)
+      if (q < nb && lane == 0) a.hid[(size_t)(b0 + q) * a.Cs + j] = relu6f(v[q] + a.b1[j]);
   }
 }
 
@@ -139,20 +165,11 @@ __global__ void __launch_bounds__(256) se_fc2_kernel(const SeArgs a) {
   for (int cc = wave; cc < kSeRows; cc += 4) {
     const int c = blockIdx.x * kSeRows + cc;
     if (c >= a.C) break;
-    float acc[kSeMaxB];
+    float v[kSeMaxB];
+    se_row_dots<T>(w2 + (size_t)c * a.Cs, shid, a.Cs, nb, lane, v);
 #pragma unroll
-    for (int q = 0; q < kSeMaxB; ++q) acc[q] = 0.f;
-    for (int j = lane; j < a.Cs; j += 64) {
-      const float w = (float)w2[(size_t)c * a.Cs + j];
-#pragma unroll
-      for (int q = 0; q < kSeMaxB; ++q)
-        if (q < nb) acc[q] += w * shid[q * a.Cs + j];
-    }
-#pragma unroll
-    for (int q = 0; q < kSeMaxB; ++q) {
-      const float v = wave_sum(acc[q]);
-      if (q < nb && lane == 0) a.gate[(size_t)(b0 + q) * a.C + c] = sigmoidf(v + a.b2[c]);
-    }
+    for (int q = 0; q < kSeMaxB; ++q)
+      if (q < nb && lane == 0) a.gate[(size_t)(b0 + q) * a.C + c] = sigmoidf(v[q] + a.b2[c]);
   }
 }
 
@@ -580,6 +597,27 @@ hipError_t launch_repack_init_mfma(int dtype, const float* src, void* dst, int O
   switch (dtype) {
     case 1: hipLaunchKernelGGL(repack_init_mfma_kernel<half_t>, grid, dim3(256), 0, s, src, (half_t*)dst, O, I); break;
     case 2: hipLaunchKernelGGL(repack_init_mfma_kernel<bf16_t>, grid, dim3(256), 0, s, src, (bf16_t*)dst, O, I); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+// final_conv for the MFMA kernel: dst[(((chunk*18 + ks)*2 + h)*4 + o)*8 + j] = W[o][chunk*32 + (ks&1)*16 + h*8 + j][tap = ks>>1]
+template <typename T>
+__global__ void repack_final_mfma_kernel(const float* src, T* dst, int O, int I) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int total = (I / 32) * 18 * 2 * 4 * 8;
+  if (i >= total) return;
+  const int j = i & 7, o = (i >> 3) & 3, h = (i >> 5) & 1, ks = (i >> 6) % 18, chunk = (i >> 6) / 18;
+  const int ci = chunk * 32 + (ks & 1) * 16 + h * 8 + j, tap = ks >> 1;
+  dst[i] = o < O ? (T)src[((size_t)o * I + ci) * 9 + tap] : (T)0.f;
+}
+hipError_t launch_repack_final_mfma(int dtype, const float* src, void* dst, int O, int I, hipStream_t s) {
+  if (O > 4 || I % 32) return hipErrorInvalidValue;
+  const int total = (I / 32) * 18 * 2 * 4 * 8;
+  dim3 grid((total + 255) / 256);
+  switch (dtype) {
+    case 1: hipLaunchKernelGGL(repack_final_mfma_kernel<half_t>, grid, dim3(256), 0, s, src, (half_t*)dst, O, I); break;
+    case 2: hipLaunchKernelGGL(repack_final_mfma_kernel<bf16_t>, grid, dim3(256), 0, s, src, (bf16_t*)dst, O, I); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();
