@@ -1,0 +1,97 @@
+"""Host-side I/O and the CLI counterparts of the reference's scripts."""
+import importlib
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import oracle
+from conftest import ROOT
+
+M = importlib.import_module("cv-diffusion-model_amd")
+
+
+def test_preprocess_postprocess_semantics():
+    rng = np.random.default_rng(0)
+    img = rng.integers(0, 256, size=(40, 56, 3), dtype=np.uint8)
+    x, orig = M.preprocess_array(img, 64)
+    assert x.shape == (1, 3, 64, 64) and x.dtype == np.float32 and orig == (40, 56)
+    assert x.min() >= -1.0 and x.max() <= 1.0
+    # normalise / denormalise is exact on uint8 at equal size (inference.py:112,128-129)
+    same, _ = M.preprocess_array(img, 56) if False else (None, None)
+    sq = rng.integers(0, 256, size=(64, 64, 3), dtype=np.uint8)
+    xs, o = M.preprocess_array(sq, 64)
+    assert np.array_equal(M.postprocess_array(xs, o), sq)
+    # out-of-range model outputs are clipped like the reference's np.clip(...).astype(uint8)
+    big = np.full((1, 3, 64, 64), 3.0, dtype=np.float32)
+    assert M.postprocess_array(big, (64, 64)).max() == 255
+
+
+@pytest.mark.parametrize("shape,out", [((37, 53), (64, 64)), ((96, 80), (32, 48)), ((64, 64), (64, 64))])
+def test_resize_geometry_matches_half_pixel_bilinear(shape, out):
+    """cv2.INTER_LINEAR's geometry == interpolate(bilinear, align_corners=False, no antialias)."""
+    rng = np.random.default_rng(1)
+    a = rng.integers(0, 256, size=shape + (3,), dtype=np.uint8)
+    r = M.resize_bilinear(a, *out)
+    t = F.interpolate(torch.from_numpy(a).permute(2, 0, 1)[None].float(), size=out, mode="bilinear", align_corners=False)
+    ref = np.floor(t[0].permute(1, 2, 0).numpy() + 0.5)
+    assert np.abs(r.astype(np.float64) - ref).max() <= 1.0
+
+
+def test_checkpoint_layouts(tmp_path):
+    spec = oracle.make_spec("small", 64)
+    sd = oracle.synth_state_dict(oracle.param_shapes(spec))
+    bare, trainer = tmp_path / "bare.pt", tmp_path / "trainer.pt"
+    torch.save(dict(sd), bare)                                                    # export.py:151-155
+    torch.save({"epoch": 3, "global_step": 77, "model_state_dict": dict(sd), "best_val_loss": 0.5,
+                "optimizer_state_dict": {}, "config": {"lr": 1e-4}}, trainer)      # trainer.py:418-434
+    for path in (bare, trainer):
+        m = M.LowLightDiffusion(unet_variant="small", image_size=64)
+        meta = M.load_checkpoint(m, str(path))
+        assert all(torch.equal(v, sd[k]) for k, v in m.state_dict().items())
+    assert meta == {"epoch": 3, "global_step": 77, "best_val_loss": 0.5}
+    with pytest.raises(ValueError):
+        M.extract_state_dict({"weights": 1})
+
+
+def test_cli_flags_match_reference():
+    """Same flag names as the reference's argparse surfaces (inference.py:30-62, benchmark.py:23-44)."""
+    inf = open(os.path.join(ROOT, "scripts", "inference.py")).read()
+    ben = open(os.path.join(ROOT, "scripts", "benchmark.py")).read()
+    for flag in ["--input", "--output", "--checkpoint", "--model", "--format", "--variant", "--image_size", "--num_steps", "--device"]:
+        assert f'"{flag}"' in inf, flag
+    for flag in ["--model", "--format", "--image_size", "--batch_size", "--num_runs", "--warmup", "--num_steps", "--device", "--threads"]:
+        assert f'"{flag}"' in ben, flag
+
+
+@pytest.mark.gpu
+def test_cli_end_to_end(tmp_path):
+    from PIL import Image
+    spec = oracle.make_spec("small", 64)
+    sd = oracle.synth_state_dict(oracle.param_shapes(spec))
+    ckpt = tmp_path / "ckpt.pt"
+    torch.save({"epoch": 1, "model_state_dict": dict(sd)}, ckpt)
+    rng = np.random.default_rng(2)
+    src = tmp_path / "in"; src.mkdir()
+    for i, (h, w) in enumerate([(48, 80), (100, 70)]):
+        Image.fromarray((rng.random((h, w, 3)) * 60).astype(np.uint8)).save(src / f"dark{i}.png")
+    dst = tmp_path / "out"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "inference.py"), "--input", str(src), "--output", str(dst),
+                        "--checkpoint", str(ckpt), "--variant", "small", "--image_size", "64", "--num_steps", "4"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    for i, (h, w) in enumerate([(48, 80), (100, 70)]):
+        out = np.asarray(Image.open(dst / f"dark{i}.png"))
+        assert out.shape == (h, w, 3) and out.dtype == np.uint8
+    bare = tmp_path / "bare.pt"
+    torch.save(dict(sd), bare)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "benchmark.py"), "--model", str(bare), "--format", "pytorch",
+                        "--image_size", "64", "--batch_size", "2", "--num_runs", "3", "--warmup", "1", "--device", "cuda"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    assert re.search(r"Mean latency:\s+[\d.]+ ms", r.stdout) and "images/s" in r.stdout
