@@ -161,14 +161,17 @@ __global__ void __launch_bounds__(WM* WN * 64) pw_gemm_kernel(const GemmArgs g) 
   constexpr int VR = BN / VEC;   // vectors per output row
   constexpr int RPP = NT / VR;   // rows per pass
   constexpr int SROWS = WM * 32; // rows staged per pass
+  constexpr int G = BM < 128 ? BM : 128;  // statistics granularity in rows (what consumers assume: pw_gemm_tile_rows)
+  constexpr int SG = BM / G;              // statistic groups per tile
   static_assert(NT % VR == 0 && VR <= 64, "epilogue mapping");
+  static_assert(SG == 1 || (RPP <= 32 && 32 % RPP == 0 && MI * 32 == G), "per-group statistics need one wave row per group");
   const int cv = tid % VR, r0 = tid / VR;
-  float bias[VEC], s1[VEC], s2[VEC];
+  float bias[VEC], s1[SG][VEC], s2[SG][VEC];
 #pragma unroll
   for (int e = 0; e < VEC; ++e) {
     bias[e] = g.bias ? g.bias[n0 + cv * VEC + e] : 0.f;
-    s1[e] = 0.f;
-    s2[e] = 0.f;
+#pragma unroll
+    for (int q = 0; q < SG; ++q) s1[q][e] = s2[q][e] = 0.f;
   }
   T* outp = reinterpret_cast<T*>(g.out);
   const T* resp = reinterpret_cast<const T*>(g.res);
@@ -184,7 +187,11 @@ __global__ void __launch_bounds__(WM* WN * 64) pw_gemm_kernel(const GemmArgs g) 
         sC[row * CP + col] = acc[pi][j][r];
       }
     __syncthreads();
-    for (int srow = r0; srow < SROWS; srow += RPP) {
+#pragma unroll
+    for (int it = 0; it < (SROWS + RPP - 1) / RPP; ++it) {
+      const int srow = r0 + it * RPP;
+      if (SROWS % RPP != 0 && srow >= SROWS) break;
+      const int grp = SG == 1 ? 0 : (it * RPP) >> 5;     // wave row == statistic group (static after unrolling)
       const int row = ((srow >> 5) * MI + pi) * 32 + (srow & 31);  // row inside the BM tile
       float v[VEC];
       const float* pc = sC + srow * CP + cv * VEC;
@@ -203,38 +210,43 @@ __global__ void __launch_bounds__(WM* WN * 64) pw_gemm_kernel(const GemmArgs g) 
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
           const float q = (float)ov[e];
-          s1[e] += q;
-          s2[e] += q * q;
+          s1[grp][e] += q;
+          s2[grp][e] += q * q;
         }
       }
     }
   }
   if (g.stats) {
-    // lanes with equal cv differ in lane bits >= log2(VR)
-#pragma unroll
-    for (int o = VR; o < 64; o <<= 1)
-#pragma unroll
-      for (int e = 0; e < VEC; ++e) {
-        s1[e] += __shfl_xor(s1[e], o, 64);
-        s2[e] += __shfl_xor(s2[e], o, 64);
-      }
     float* red = sC + SROWS * CP;  // [waves][2][BN]
     constexpr int NW = NT / 64;
-    if (lane < VR) {
+    const int ntiles = g.P / G;
 #pragma unroll
-      for (int e = 0; e < VEC; ++e) {
-        red[(wave * 2 + 0) * BN + cv * VEC + e] = s1[e];
-        red[(wave * 2 + 1) * BN + cv * VEC + e] = s2[e];
+    for (int q = 0; q < SG; ++q) {
+      // lanes with equal cv differ in lane bits >= log2(VR)
+#pragma unroll
+      for (int o = VR; o < 64; o <<= 1)
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          s1[q][e] += __shfl_xor(s1[q][e], o, 64);
+          s2[q][e] += __shfl_xor(s2[q][e], o, 64);
+        }
+      if (q) __syncthreads();
+      if (lane < VR) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          red[(wave * 2 + 0) * BN + cv * VEC + e] = s1[q][e];
+          red[(wave * 2 + 1) * BN + cv * VEC + e] = s2[q][e];
+        }
       }
-    }
-    __syncthreads();
-    const int ntiles = g.P / BM, tile = (m0 % g.P) / BM;
-    for (int i = tid; i < 2 * BN; i += NT) {
-      const int which = i / BN, c = i % BN;
-      float t = 0.f;
+      __syncthreads();
+      const int tile = (m0 % g.P) / G + q;
+      for (int i = tid; i < 2 * BN; i += NT) {
+        const int which = i / BN, c = i % BN;
+        float t = 0.f;
 #pragma unroll
-      for (int w = 0; w < NW; ++w) t += red[(w * 2 + which) * BN + c];
-      g.stats[((size_t)(img * ntiles + tile) * 2 + which) * g.N + n0 + c] = t;
+        for (int w = 0; w < NW; ++w) t += red[(w * 2 + which) * BN + c];
+        g.stats[((size_t)(img * ntiles + tile) * 2 + which) * g.N + n0 + c] = t;
+      }
     }
   }
 }
@@ -260,7 +272,7 @@ static hipError_t launch_cfg(const GemmArgs& a, hipStream_t s) {
 
 int pw_gemm_tile_rows(int P) { return (P % 128 == 0) ? 128 : 64; }
 
-// tuning knob for tools/gpu_tune.py (0 = automatic)
+// tuning knobs for tools/gpu_tune.py (0 = automatic)
 static int g_force_bk = 0;
 void pw_gemm_force_bk(int bk) { g_force_bk = bk; }
 

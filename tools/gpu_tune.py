@@ -91,19 +91,19 @@ SHAPES = [  # (name, kind, P, segs, N)   small@256, B=32
 if __name__ == "__main__":
     B = 32
     if "gemm" in sys.argv[1:]:
-        knobs = [("normal", 0), ("noloads", 1), ("nostage", 3), ("normal2", 0)]
+        knobs = [("auto", 0), ("bk32", 32)]
         print(f"{'shape':28s} " + " ".join(f"{k:>16s}" for k, _ in knobs))
         tot = {k: 0.0 for k, _ in knobs}
         for name, kind, P, segs, n in SHAPES:
             row = []
             for k, v in knobs:
-                L.llie_tune(b"gemm_ablate", v)
+                L.llie_tune(b"gemm_bk", v)
                 us, gbs, tf = gemm(kind, B * P, segs, n, P)
                 tot[k] += us
                 row.append(f"{us:8.1f}us {tf:5.0f}TF")
             print(f"{name:28s} " + " ".join(f"{r:>16s}" for r in row), flush=True)
         print("sum(us):", {k: round(v, 1) for k, v in tot.items()})
-        L.llie_tune(b"gemm_ablate", 0)
+        L.llie_tune(b"gemm_bk", 0)
     if "dw" in sys.argv[1:]:
         for rep in range(2):
             for H, Cc in [(256, 128), (256, 384), (128, 768), (64, 1536)]:
