@@ -21,13 +21,13 @@ namespace llie {
 
 constexpr int kDwPF = 4;  // rows of global loads kept in flight per thread
 
-template <typename T, int TX>
+template <typename T, int TX, int PFV>
 __global__ void __launch_bounds__(8 * TX) dwconv3x3_kernel(const DwArgs a, const int TYL, const int dbg) {
   constexpr int NT = 8 * TX;
   constexpr int VEC = Elem<T>::VEC;
   constexpr int CC = 8 * VEC;  // channels per workgroup
   constexpr int PW = TX + 2;
-  constexpr int PF = kDwPF;
+  constexpr int PF = PFV;
   typedef typename Elem<T>::vec_t vec_t;
   __shared__ vec_t ring[2][PW * 8];
   __shared__ float red[(NT / 64) * CC];
@@ -161,9 +161,9 @@ __global__ void __launch_bounds__(8 * TX) dwconv3x3_kernel(const DwArgs a, const
 }
 
 static int g_dw_dbg = 0;
-void dwconv_debug(int v) { g_dw_dbg = v; }
+void dwconv_debug(int v) { g_dw_dbg = v; }  // bits 0-1: timing ablations
 static int dw_tx(int W) { return (W % 32 == 0) ? 32 : ((W % 16 == 0) ? 16 : 8); }
-static int dw_tyl(int H) { return (H % 32 == 0) ? 32 : ((H % 16 == 0) ? 16 : 8); }
+static int dw_tyl(int H) { return (H % 64 == 0) ? 64 : ((H % 32 == 0) ? 32 : ((H % 16 == 0) ? 16 : 8)); }
 int dwconv_ntiles(int H, int W) { return (H / dw_tyl(H)) * (W / dw_tx(W)); }
 
 template <typename T>
@@ -172,9 +172,9 @@ static hipError_t launch_dw_t(const DwArgs& a, hipStream_t s) {
   if (a.C % CC || a.H % 8 || a.W % 8) return hipErrorInvalidValue;
   const int tx = dw_tx(a.W), tyl = dw_tyl(a.H);
   dim3 grid((a.W / tx) * (a.H / tyl), a.C / CC, a.B);
-  if (tx == 32) hipLaunchKernelGGL((dwconv3x3_kernel<T, 32>), grid, dim3(256), 0, s, a, tyl, g_dw_dbg);
-  else if (tx == 16) hipLaunchKernelGGL((dwconv3x3_kernel<T, 16>), grid, dim3(128), 0, s, a, tyl, g_dw_dbg);
-  else hipLaunchKernelGGL((dwconv3x3_kernel<T, 8>), grid, dim3(64), 0, s, a, tyl, g_dw_dbg);
+  if (tx == 32) hipLaunchKernelGGL((dwconv3x3_kernel<T, 32, kDwPF>), grid, dim3(256), 0, s, a, tyl, g_dw_dbg & 3);
+  else if (tx == 16) hipLaunchKernelGGL((dwconv3x3_kernel<T, 16, kDwPF>), grid, dim3(128), 0, s, a, tyl, g_dw_dbg & 3);
+  else hipLaunchKernelGGL((dwconv3x3_kernel<T, 8, kDwPF>), grid, dim3(64), 0, s, a, tyl, g_dw_dbg & 3);
   return hipGetLastError();
 }
 

@@ -114,3 +114,47 @@ if __name__ == "__main__":
                     row.append(f"m{mode}: {us:7.1f}us {gbs:5.0f}GB/s")
                 print(f"dw {H}x{H} C={Cc}: " + " | ".join(row), flush=True)
         L.llie_tune(b"dw_ablate", 0)
+
+
+def chain(B, Bc, P, H, cin, hid, cout, iters=5):
+    """K1 -> depthwise -> K3 of one inverted-residual block over B images in chunks of Bc (fp16):
+    does keeping a chunk's hidden tensors in the Infinity Cache beat full-batch launches?"""
+    tdt = torch.float16
+    x = torch.randn(B * P, cin, device=dev, dtype=tdt)
+    w1 = torch.randn(hid, cin, device=dev, dtype=tdt) * 0.05
+    w3 = torch.randn(cout, hid, device=dev, dtype=tdt) * 0.05
+    h1 = torch.empty(Bc * P, hid, device=dev, dtype=tdt)
+    h2 = torch.empty(Bc * P, hid, device=dev, dtype=tdt)
+    y = torch.empty(B * P, cout, device=dev, dtype=tdt)
+    sc = torch.rand(B, max(cin, hid), device=dev) + 0.5
+    bi = torch.randn(B, max(cin, hid), device=dev) * 0.1
+    wd = torch.randn(9, hid, device=dev) * 0.3
+    tiles = P // L.llie_pw_gemm_tile_rows(P)
+    st1 = torch.empty(B * tiles * 2 * hid, device=dev)
+    st3 = torch.empty(B * tiles * 2 * cout, device=dev)
+    pool = torch.empty(B * L.llie_dwconv3x3_tiles(H, H) * hid, device=dev)
+    es = 2
+
+    def run():
+        for b0 in range(0, B, Bc):
+            xo = x.data_ptr() + b0 * P * cin * es
+            s1 = (N.GemmSeg * 1)(N.GemmSeg(xo, cin, sc.data_ptr() + b0 * sc.shape[1] * 4, bi.data_ptr() + b0 * sc.shape[1] * 4, sc.shape[1], 1))
+            N.check(L.llie_pw_gemm(1, s1, 1, w1.data_ptr(), None, None, h1.data_ptr(), st1.data_ptr(), Bc * P, hid, P, st()))
+            N.check(L.llie_dwconv3x3(1, h1.data_ptr(), h2.data_ptr(), sc.data_ptr() + b0 * sc.shape[1] * 4, bi.data_ptr() + b0 * sc.shape[1] * 4,
+                                     wd.data_ptr(), pool.data_ptr(), Bc, H, H, hid, st()))
+            s3 = (N.GemmSeg * 1)(N.GemmSeg(h2.data_ptr(), hid, sc.data_ptr() + b0 * sc.shape[1] * 4, None, sc.shape[1], 0))
+            N.check(L.llie_pw_gemm(1, s3, 1, w3.data_ptr(), None, xo if cin == cout else None,
+                                   y.data_ptr() + b0 * P * cout * es, st3.data_ptr(), Bc * P, cout, P, st()))
+    return time_it(run, iters)
+
+
+if __name__ == "__main__" and "chain" in sys.argv[1:]:
+    for name, P, H, cin, hid, cout in [("enc0 32-128-32 @256", 65536, 256, 32, 128, 32), ("dec3.0 96-384-32 @256", 65536, 256, 96, 384, 32),
+                                        ("enc1.1 64-256-64 @128", 16384, 128, 64, 256, 64), ("dec2.0 192-768-64 @128", 16384, 128, 192, 768, 64),
+                                        ("mid 256-1024-256 @32", 1024, 32, 256, 1024, 256)]:
+        row = []
+        for rep in range(2):
+            for Bc in (32, 16, 8, 4, 2):
+                us = chain(32, Bc, P, H, cin, hid, cout)
+                row.append(f"Bc={Bc}: {us:7.0f}us")
+        print(f"{name:26s} " + " | ".join(row), flush=True)
