@@ -172,29 +172,35 @@ def main() -> None:
 
 
 def roofline(handle, native, args) -> dict:
-    """Roofline of the dominant kernel class, from HIP events recorded on the launch stream during the
-    timed region (engine hooks llie_profile_begin/end).  `achieved` = algorithmic bytes of the recorded
-    launches / their summed device time; the per-launch byte model is in DESIGN.md section 4
-    (depthwise: read h1 + write h2 = 2*B*P*Chid*elem; pointwise GEMM: A + out (+residual) + W)."""
-    names = {native.K_DW: "dwconv3x3_kernel", native.K_GEMM: "pw_gemm_kernel", native.K_CONV3: "conv3x3_kernel",
-             native.K_SE: "se_pool/fc1/fc2 kernels"}
-    stats = {}
-    for cls in names:
-        ms, n, nbytes = handle.profile_end(cls)
-        stats[cls] = (ms, n, nbytes)
-    dom = max(stats, key=lambda c: stats[c][0])
-    ms, n, nbytes = stats[dom]
+    """Roofline of the dominant kernel, from HIP events recorded on the launch stream during the timed
+    region (engine hooks llie_profile_begin / llie_profile_report, aggregated per kernel name -- the
+    granularity of `rocprofv3 --kernel-trace --stats`).  `achieved` = algorithmic bytes of that
+    kernel's recorded launches / their summed device time (byte model: DESIGN.md section 3;
+    depthwise: read h1 + write h2 = 2*B*P*Chid*elem; pointwise GEMM: A + out (+residual) + W).
+    `traffic` = measured HBM bytes per launch from the committed PMC passes of this same command
+    (profiles/r01/pmc_traffic.json; FETCH_SIZE x2 + WRITE_SIZE, see tools/pmc_summary.py), else null."""
+    rep = handle.profile_report()
+    if not rep:
+        return None
+    dom = max(rep, key=lambda k: rep[k][0])
+    ms, n, nbytes = rep[dom]
     achieved = nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-    out = {"bound": "hbm", "kernel": names[dom], "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-           "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-           "launches": n, "avg_launch_us": round(1e3 * ms / max(n, 1), 2),
-           "alg_bytes_per_launch": int(nbytes / max(n, 1)),
-           "classes": {names[c]: {"ms": round(v[0], 3), "launches": v[1],
-                                  "GBps": round(v[2] / (v[0] * 1e-3) / 1e9, 1) if v[0] > 0 else None}
-                       for c, v in stats.items()}}
-    # whole-forward view: SURVEY.md 8d algorithmic bytes of one UNet forward at this batch / dtype
-    out["forward_alg_bytes"] = handle.algorithmic_bytes(args.batch)
-    return out
+    traffic = None
+    pmc = os.path.join(ROOT, "profiles", "r01", "pmc_traffic.json")
+    default_cfg = (args.variant, args.image_size, args.batch, args.lcm_steps, args.dtype) == ("small", 256, 32, 4, "fp16")
+    if default_cfg and os.path.exists(pmc):
+        k = json.load(open(pmc)).get("kernels", {}).get(dom)
+        if k:
+            traffic = k["hbm_bytes_per_launch"]
+    total_ms = sum(v[0] for v in rep.values())
+    return {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+            "launches": n, "avg_launch_us": round(1e3 * ms / max(n, 1), 2), "alg_bytes_per_launch": int(nbytes / max(n, 1)),
+            "share_of_profiled_time": round(ms / total_ms, 3),
+            "kernels": {k: {"ms": round(v[0], 3), "launches": v[1], "avg_us": round(1e3 * v[0] / v[1], 2),
+                            "GBps": round(v[2] / (v[0] * 1e-3) / 1e9, 1) if v[0] > 0 else None}
+                        for k, v in sorted(rep.items(), key=lambda kv: -kv[1][0])},
+            "forward_alg_bytes": handle.algorithmic_bytes(args.batch)}
 
 
 if __name__ == "__main__":

@@ -23,7 +23,7 @@ EXPORTS = [
     "llie_load_param", "llie_params_loaded", "llie_workspace_bytes", "llie_unet_forward", "llie_module_forward",
     "llie_lcm_step", "llie_add_noise", "llie_enhance", "llie_algorithmic_bytes", "llie_flops",
     "llie_profile_begin", "llie_profile_end", "llie_enhance_workspace_bytes",
-    "llie_pw_gemm", "llie_pw_gemm_tile_rows", "llie_dwconv3x3", "llie_dwconv3x3_tiles", "llie_tune",
+    "llie_profile_report", "llie_pw_gemm", "llie_pw_gemm_tile_rows", "llie_dwconv3x3", "llie_dwconv3x3_tiles", "llie_tune",
 ]
 K_GEMM, K_DW, K_CONV3, K_SE = 1, 2, 4, 8
 
@@ -96,6 +96,7 @@ def lib() -> C.CDLL:
     L.llie_dwconv3x3.argtypes = [ci, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, vp]
     L.llie_dwconv3x3_tiles.argtypes = [ci, ci]
     L.llie_tune.argtypes = [C.c_char_p, ci]
+    L.llie_profile_report.argtypes = [vp, C.c_char_p, C.c_size_t]
     L.llie_profile_begin.argtypes = [vp, ci]
     L.llie_profile_end.argtypes = [vp, ci, C.POINTER(C.c_double), C.POINTER(i64), C.POINTER(i64)]
     _lib = L
@@ -187,6 +188,16 @@ class Handle:
 
     def profile_begin(self, class_mask: int) -> None:
         check(self._L.llie_profile_begin(self.h, class_mask), "profile_begin")
+
+    def profile_report(self):
+        """-> {kernel name: (total device ms, launches, algorithmic bytes)} of the recorded launches."""
+        buf = C.create_string_buffer(1 << 16)
+        check(self._L.llie_profile_report(self.h, buf, len(buf)), "profile_report")
+        out = {}
+        for line in buf.value.decode().splitlines():
+            name, ms, n, b = line.split("\t")
+            out[name] = (float(ms), int(n), int(b))
+        return out
 
     def profile_end(self, kernel_class: int):
         """-> (total device ms, launches, algorithmic bytes) of the recorded launches of `kernel_class`."""

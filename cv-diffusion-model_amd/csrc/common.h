@@ -22,6 +22,11 @@ constexpr int kWave = 64;
 
 // ---------------------------------------------------------------------------------------------
 // Element traits: VEC = elements per 16-byte lane vector.
+template <typename T> struct TypeName;
+template <> struct TypeName<float> { static constexpr const char* value = "float"; };
+template <> struct TypeName<_Float16> { static constexpr const char* value = "_Float16"; };
+template <> struct TypeName<__bf16> { static constexpr const char* value = "__bf16"; };
+
 template <typename T> struct Elem;
 template <> struct Elem<float> {
   static constexpr int VEC = 4;

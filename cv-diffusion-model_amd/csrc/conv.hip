@@ -6,6 +6,7 @@
 //   Downsample  (efficient_unet.py:367)  3x3 stride 2       } implicit GEMM on MFMA: M = 8 x TW output pixels,
 //   Upsample    (efficient_unet.py:383-384) bilinear x2 + 3x3 } N = Cout tile, K = 9 taps x Cin; the upsampled
 //               halo patch is interpolated on the fly into LDS, so the 4x tensor never reaches HBM.
+#include <string>
 #include <type_traits>
 
 #include "common.h"
@@ -594,6 +595,10 @@ static hipError_t launch_conv_cfg(const Conv3Args& a, hipStream_t s) {
   }
   const int Ho = MODE == 0 ? a.Hi / 2 : a.Hi * 2, Wo = MODE == 0 ? a.Wi / 2 : a.Wi * 2;
   const unsigned grid = (unsigned)(a.B * (Ho / 8) * (Wo / TW) * (a.Cout / BN));
+  static const std::string name = std::string("conv3x3_kernel<") + TypeName<T>::value + ", " + std::to_string(MODE) + ", " +
+                                  std::to_string(TW) + ", " + std::to_string(BN) + ", " + std::to_string(WM) + ", " +
+                                  std::to_string(WN) + ">";
+  note_kernel(name.c_str());
   hipLaunchKernelGGL((conv3x3_kernel<T, MODE, TW, BN, WM, WN>), dim3(grid), dim3(NT), lds, s, a);
   return hipGetLastError();
 }

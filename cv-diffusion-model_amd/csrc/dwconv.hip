@@ -14,6 +14,8 @@
 //     and feeds three rolling output-row accumulators, so vertical reuse lives in registers.
 // LDS per workgroup is ~9 KB, so occupancy is set by registers, not LDS; halo re-reads are 2 rows per
 // TYL and 2 columns per TX.
+#include <string>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -172,6 +174,10 @@ static hipError_t launch_dw_t(const DwArgs& a, hipStream_t s) {
   if (a.C % CC || a.H % 8 || a.W % 8) return hipErrorInvalidValue;
   const int tx = dw_tx(a.W), tyl = dw_tyl(a.H);
   dim3 grid((a.W / tx) * (a.H / tyl), a.C / CC, a.B);
+  static const std::string names[3] = {std::string("dwconv3x3_kernel<") + TypeName<T>::value + ", 32, 4>",
+                                       std::string("dwconv3x3_kernel<") + TypeName<T>::value + ", 16, 4>",
+                                       std::string("dwconv3x3_kernel<") + TypeName<T>::value + ", 8, 4>"};
+  note_kernel(names[tx == 32 ? 0 : (tx == 16 ? 1 : 2)].c_str());
   if (tx == 32) hipLaunchKernelGGL((dwconv3x3_kernel<T, 32, kDwPF>), grid, dim3(256), 0, s, a, tyl, g_dw_dbg & 3);
   else if (tx == 16) hipLaunchKernelGGL((dwconv3x3_kernel<T, 16, kDwPF>), grid, dim3(128), 0, s, a, tyl, g_dw_dbg & 3);
   else hipLaunchKernelGGL((dwconv3x3_kernel<T, 8, kDwPF>), grid, dim3(64), 0, s, a, tyl, g_dw_dbg & 3);

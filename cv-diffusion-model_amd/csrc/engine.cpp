@@ -147,7 +147,7 @@ struct llie_ctx {
   hipStream_t cap_stream = nullptr;  // side stream used only to record captures (the legacy null stream cannot capture)
   // per-kernel-class HIP-event profiling (llie_profile_begin / llie_profile_end)
   int prof_mask = 0;
-  struct ProfRec { int cls; int64_t bytes; hipEvent_t e0, e1; };
+  struct ProfRec { int cls; int64_t bytes; hipEvent_t e0, e1; const char* name; };
   std::vector<ProfRec> prof;
   std::vector<hipEvent_t> event_pool;
   hipEvent_t get_event() {
@@ -410,11 +410,12 @@ struct Run {
   // launch `f` bracketed by HIP events on the launch stream when its class is being profiled
   template <typename F> void timed(int cls, int64_t bytes, F&& f) {
     if (!(c->prof_mask & cls) || c->prof.size() >= 8192) { chk(f()); return; }
-    llie_ctx::ProfRec r{cls, bytes, c->get_event(), c->get_event()};
+    llie_ctx::ProfRec r{cls, bytes, c->get_event(), c->get_event(), ""};
     if (!r.e0 || !r.e1) { chk(f()); return; }
     chk(hipEventRecord(r.e0, s));
     chk(f());
     chk(hipEventRecord(r.e1, s));
+    r.name = last_kernel();  // static storage: launchers pass string literals / function-local statics
     c->prof.push_back(r);
   }
 
@@ -1117,6 +1118,30 @@ int llie_profile_end(llie_ctx* c, int kernel_class, double* total_ms, int64_t* l
   if (total_ms) *total_ms = ms;
   if (launches) *launches = n;
   if (alg_bytes) *alg_bytes = bytes;
+  return LLIE_OK;
+}
+
+int llie_profile_report(llie_ctx* c, char* buf, size_t cap) {
+  if (!c || !buf || cap < 2) return LLIE_ERR_ARG;
+  c->prof_mask = 0;
+  struct Agg { double ms = 0; int64_t n = 0, bytes = 0; };
+  std::map<std::string, Agg> agg;
+  for (auto& r : c->prof) {
+    hipError_t e = hipEventSynchronize(r.e1);
+    float t = 0.f;
+    if (e == hipSuccess) e = hipEventElapsedTime(&t, r.e0, r.e1);
+    if (e != hipSuccess) { set_err("profile: %s", hipGetErrorString(e)); return (int)e; }
+    Agg& a = agg[r.name ? r.name : "?"];
+    a.ms += t; a.n += 1; a.bytes += r.bytes;
+  }
+  std::string out;
+  char line[512];
+  for (auto& kv : agg) {
+    snprintf(line, sizeof line, "%s\t%.6f\t%lld\t%lld\n", kv.first.c_str(), kv.second.ms, (long long)kv.second.n, (long long)kv.second.bytes);
+    out += line;
+  }
+  if (out.size() + 1 > cap) { set_err("profile report buffer too small"); return LLIE_ERR_ARG; }
+  memcpy(buf, out.c_str(), out.size() + 1);
   return LLIE_OK;
 }
 

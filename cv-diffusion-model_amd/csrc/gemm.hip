@@ -10,6 +10,8 @@
 //                                                    (sum, sumsq) slab for the next GroupNorm.
 // A rows are NHWC pixels (K contiguous), W is [N][K] (K contiguous): both MFMA operands read 16
 // contiguous K-elements per lane.  fp32 accumulation always; T = float uses the exact-f32 MFMA.
+#include <string>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -266,6 +268,10 @@ static hipError_t launch_cfg(const GemmArgs& a, hipStream_t s) {
     attr_done = true;
   }
   const unsigned grid = (unsigned)((a.M / BM) * (a.N / BN));
+  static const std::string name = std::string("pw_gemm_kernel<") + TypeName<T>::value + ", " + std::to_string(BM) + ", " +
+                                  std::to_string(BN) + ", " + std::to_string(WM) + ", " + std::to_string(WN) + ", " +
+                                  std::to_string(BK) + ">";
+  note_kernel(name.c_str());
   hipLaunchKernelGGL((pw_gemm_kernel<T, BM, BN, WM, WN, BK>), dim3(grid), dim3(NT), lds, s, a);
   return hipGetLastError();
 }

@@ -8,6 +8,11 @@ namespace llie {
 
 enum Act : int { ACT_NONE = 0, ACT_RELU6 = 1, ACT_SILU = 2 };
 
+// Launchers of the profiled kernel classes record the name of the kernel they dispatched (template
+// arguments included, as rocprofv3 prints them) so that llie_profile_report can aggregate per kernel.
+void note_kernel(const char* name);
+const char* last_kernel();
+
 // Per-channel statistics slab written by producers for the next GroupNorm:
 //   slab[((b * ntiles + tile) * 2 + {0: sum, 1: sum of squares}) * C + c]   (fp32)
 // `tile` enumerates the producer's row tiles inside one image.  gn_finalize reduces slabs in a fixed

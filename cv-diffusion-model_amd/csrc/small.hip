@@ -6,6 +6,10 @@
 
 namespace llie {
 
+static thread_local const char* g_last_kernel = "";
+void note_kernel(const char* name) { g_last_kernel = name; }
+const char* last_kernel() { return g_last_kernel; }
+
 // =============================================================================================
 // GroupNorm finalize: slabs of per-channel (sum, sumsq) -> per-(image, channel) affine.
 // nn.GroupNorm(min(32,C), C) call sites: efficient_unet.py:170-171,263,268,528 (biased variance,
@@ -174,6 +178,7 @@ __global__ void __launch_bounds__(256) se_fc2_kernel(const SeArgs a) {
 }
 
 hipError_t launch_se_fc1(int dtype, const SeArgs& a, hipStream_t s) {
+  note_kernel("se_pool_kernel+se_fc1_kernel+se_fc2_kernel");
   hipLaunchKernelGGL(se_pool_kernel, dim3((a.C + 63) / 64, a.B), dim3(256), 0, s, a);
   dim3 grid((a.Cs + kSeRows - 1) / kSeRows, (a.B + kSeMaxB - 1) / kSeMaxB);
   const size_t lds = (size_t)kSeMaxB * a.C * 4;

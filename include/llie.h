@@ -182,6 +182,9 @@ enum llie_kernel_class {
 };
 int llie_profile_begin(llie_ctx* ctx, int class_mask);
 int llie_profile_end(llie_ctx* ctx, int kernel_class, double* total_ms, int64_t* launches, int64_t* algorithmic_bytes);
+/* Same data aggregated per kernel NAME (template arguments included, the granularity of
+ * `rocprofv3 --kernel-trace --stats`): writes lines "name\tms\tlaunches\talgorithmic_bytes\n" into buf. */
+int llie_profile_report(llie_ctx* ctx, char* buf, size_t cap);
 
 /* llie_algorithmic_bytes returns the roofline numerator of SURVEY.md 8d for one
  * UNet forward of `batch` images at the handle's dtype (activation traffic + weights once). */
