@@ -10,25 +10,38 @@ import collections
 import csv
 import glob
 import json
-import subprocess
 import sys
 
 
 def demangle(names):
-    out = subprocess.run(["c++filt"], input="\n".join(names), capture_output=True, text=True).stdout.splitlines()
+    """Minimal Itanium demangler for this library's kernels: _ZN4llie<len><name>[I<args>E]Ev... with
+    template arguments f / DF16_ / DF16b / Li<N>E (binutils' c++filt does not know DF16_)."""
+    import re
     res = {}
-    for m, d in zip(names, out):
-        d = d.replace("void llie::", "").replace("llie::", "")
-        depth, cut = 0, len(d)
-        for i, ch in enumerate(d):           # drop the argument list, keep template arguments
-            if ch == "<":
-                depth += 1
-            elif ch == ">":
-                depth -= 1
-            elif ch == "(" and depth == 0:
-                cut = i
-                break
-        res[m] = d[:cut].strip()
+    for m in names:
+        mm = re.match(r"_ZN4llie(\d+)", m)
+        if not mm:
+            res[m] = re.sub(r"\(.*", "", m.replace("void llie::", "").replace("llie::", "")).strip()
+            continue
+        n = int(mm.group(1))
+        name = m[mm.end():mm.end() + n]
+        rest = m[mm.end() + n:]
+        args = []
+        if rest.startswith("I"):
+            i = 1
+            while i < len(rest) and rest[i] != "E":
+                if rest.startswith("DF16_", i):
+                    args.append("_Float16"); i += 5
+                elif rest.startswith("DF16b", i):
+                    args.append("__bf16"); i += 5
+                elif rest[i] == "f":
+                    args.append("float"); i += 1
+                elif rest.startswith("Li", i):
+                    j = rest.index("E", i)
+                    args.append(rest[i + 2:j]); i = j + 1
+                else:
+                    args.append("?"); i += 1
+        res[m] = name + ("<" + ", ".join(args) + ">" if args else "")
     return res
 
 
