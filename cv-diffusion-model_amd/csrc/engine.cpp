@@ -393,6 +393,12 @@ int build_module(llie_ctx* c) {
 
 // ---------------------------------------------------------------------------------------------
 // Run helpers.  In dry mode nothing is launched; only the arena is exercised.
+// Fused expand+depthwise ("recompute" form, dwx.hip) for 2-byte dtypes.  Numerically equivalent, but as
+// built it is slower than the unfused pair on MI355X (6.2 vs 3.6 ms/forward for the depthwise class at
+// small@256 B=32 fp16; K1 without stores only drops 5.0 -> 4.6 ms), so it is opt-in: LLIE_DWX=1 or
+// llie_tune("dwx", 1).  See DESIGN.md section 7.
+bool g_use_dwx = getenv("LLIE_DWX") != nullptr;
+
 struct Run {
   llie_ctx* c;
   Arena* ar;
@@ -457,8 +463,14 @@ struct Run {
     const int BM = pw_gemm_tile_rows(P);
     size_t as1, ab1;
     gn(x0, x1, w.n1g, w.n1b, nullptr, 0, as1, ab1);
+    // Recompute form (2-byte T, narrow inputs): K1 only produces h1's statistics and the fused
+    // expand+depthwise kernel rebuilds h1 on the fly, so the 4x-expanded tensor never touches HBM.
+    const bool fused = g_use_dwx && dwx_supported(dt, w.cin, w.hid, H, W);
     // K1: expand with norm1 + ReLU6 prologue
-    Tens h1 = new_tens(w.hid, H, W, P / BM);
+    Tens h1;
+    h1.C = w.hid; h1.H = H; h1.W = W; h1.ntiles = P / BM; h1.valid = true;
+    h1.off = fused ? 0 : ar->alloc((size_t)B * P * w.hid * es());
+    h1.slab = ar->alloc((size_t)B * h1.ntiles * 2 * w.hid * 4);
     if (!dry) {
       GemmArgs g{};
       g.seg[0] = GemmSeg{p(x0.off), x0.C, p<float>(as1), p<float>(ab1), w.cin, ACT_RELU6};
@@ -467,12 +479,11 @@ struct Run {
         g.seg[1] = GemmSeg{p(x1->off), x1->C, p<float>(as1) + x0.C, p<float>(ab1) + x0.C, w.cin, ACT_RELU6};
         g.nseg = 2;
       }
-      g.w = wptr(w.w_expand); g.out = p(h1.off); g.stats = p<float>(h1.slab);
-      g.M = M; g.N = w.hid; g.K = w.cin; g.P = P;
-      timed(LLIE_K_GEMM, ((int64_t)M * (w.cin + w.hid) + (int64_t)w.hid * w.cin) * (int64_t)es(),
+      g.w = wptr(w.w_expand); g.out = fused ? nullptr : p(h1.off); g.stats = p<float>(h1.slab);
+      g.M = M; g.N = w.hid; g.K = w.cin; g.P = P; g.nostore = fused ? 1 : 0;
+      timed(LLIE_K_GEMM, ((int64_t)M * (w.cin + (fused ? 0 : w.hid)) + (int64_t)w.hid * w.cin) * (int64_t)es(),
             [&] { return launch_pw_gemm(dt, g, s); });
     }
-    ar->free(as1); ar->free(ab1);
     // norm2 + FiLM folded into one affine
     size_t as2, ab2;
     gn(h1, nullptr, w.n2g, w.n2b, film ? film + w.film_off : nullptr, film_stride, as2, ab2);
@@ -481,12 +492,23 @@ struct Run {
     const size_t h2 = ar->alloc((size_t)M * w.hid * es());
     const size_t pool = ar->alloc((size_t)B * dnt * w.hid * 4);
     if (!dry) {
-      DwArgs d{};
-      d.in = p(h1.off); d.out = p(h2); d.as = p<float>(as2); d.ab = p<float>(ab2);
-      d.w = wptr<float>(w.w_dw); d.pool = p<float>(pool); d.B = B; d.H = H; d.W = W; d.C = w.hid;
-      timed(LLIE_K_DW, 2LL * M * w.hid * (int64_t)es(), [&] { return launch_dwconv3x3(dt, d, s); });
+      if (fused) {
+        DwxArgs d{};
+        d.x0 = p(x0.off); d.c0 = x0.C; d.x1 = x1 ? p(x1->off) : nullptr; d.c1 = x1 ? x1->C : 0;
+        d.as1 = p<float>(as1); d.ab1 = p<float>(ab1); d.w1 = wptr(w.w_expand);
+        d.as2 = p<float>(as2); d.ab2 = p<float>(ab2); d.wd = wptr<float>(w.w_dw);
+        d.out = p(h2); d.pool = p<float>(pool); d.B = B; d.H = H; d.W = W; d.Chid = w.hid;
+        timed(LLIE_K_DW, (int64_t)M * (w.cin + w.hid) * (int64_t)es(), [&] { return launch_dwx(dt, d, s); });
+      } else {
+        DwArgs d{};
+        d.in = p(h1.off); d.out = p(h2); d.as = p<float>(as2); d.ab = p<float>(ab2);
+        d.w = wptr<float>(w.w_dw); d.pool = p<float>(pool); d.B = B; d.H = H; d.W = W; d.C = w.hid;
+        timed(LLIE_K_DW, 2LL * M * w.hid * (int64_t)es(), [&] { return launch_dwconv3x3(dt, d, s); });
+      }
     }
-    free_tens(h1);
+    ar->free(as1); ar->free(ab1);
+    if (!fused) ar->free(h1.off);
+    ar->free(h1.slab);
     ar->free(as2); ar->free(ab2);
     // SE MLP
     const size_t sehid = ar->alloc((size_t)B * w.sq * 4), gate = ar->alloc((size_t)B * w.hid * 4);
@@ -1089,6 +1111,7 @@ int llie_pw_gemm_tile_rows(int P) { return pw_gemm_tile_rows(P); }
 int llie_tune(const char* knob, int value) {
   if (!knob) return LLIE_ERR_ARG;
   if (!strcmp(knob, "gemm_bk")) { pw_gemm_force_bk(value); return LLIE_OK; }
+  if (!strcmp(knob, "dwx")) { g_use_dwx = value != 0; return LLIE_OK; }
   if (!strcmp(knob, "gemm_ablate")) { pw_gemm_debug(value); return LLIE_OK; }
   if (!strcmp(knob, "dw_ablate")) { dwconv_debug(value); return LLIE_OK; }
   return LLIE_ERR_ARG;

@@ -207,7 +207,7 @@ __global__ void __launch_bounds__(WM* WN * 64) pw_gemm_kernel(const GemmArgs g) 
         for (int e = 0; e < VEC; ++e) v[e] += rr[e];
       }
       vec_t ov = f32_to_vec<T>(v);
-      st_vec<T>(outp + o, ov);
+      if (!g.nostore) st_vec<T>(outp + o, ov);  // nostore: statistics-only pass (the consumer recomputes the tensor)
       if (g.stats) {
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
@@ -305,6 +305,7 @@ void pw_gemm_debug(int v) { g_gemm_dbg = v; }
 hipError_t launch_pw_gemm(int dtype, const GemmArgs& a0, hipStream_t s) {
   GemmArgs a = a0;
   a.dbg = g_gemm_dbg;
+  if (a.nostore && (!a.stats || a.res)) return hipErrorInvalidValue;
   // host-side shape contract of the kernel (checked before any launch: an out-of-contract shape
   // would index out of bounds on the device)
   if (a.nseg < 1 || a.nseg > 3 || a.N % 32 || a.K % 32 || a.P % 64 || a.M % a.P) return hipErrorInvalidValue;

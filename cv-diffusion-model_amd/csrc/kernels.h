@@ -45,6 +45,7 @@ struct GemmArgs {
   float* stats;       // slab of out or null
   int M, N, K;        // K = sum of seg ch
   int P;              // rows (pixels) per image; M = B * P
+  int nostore;        // 1: compute and write only the statistics slab (out may be null)
   int dbg;            // timing ablations (set by the launcher from pw_gemm_debug; 0 in production)
 };
 hipError_t launch_pw_gemm(int dtype, const GemmArgs& a, hipStream_t s);
@@ -82,6 +83,21 @@ struct DwArgs {
   int B, H, W, C;
 };
 hipError_t launch_dwconv3x3(int dtype, const DwArgs& a, hipStream_t s);
+
+// Fused expand + depthwise ("recompute" form, 2-byte T only): h2 = dw3x3(relu6(aff2(W1 . relu6(aff1(x))))).
+// The 4x-expanded tensor h1 is never stored: every workgroup recomputes the rows it needs with MFMA
+// from the narrow block input x (virtual concat of up to two NHWC tensors).
+struct DwxArgs {
+  const void* x0; const void* x1; int c0, c1;   // Cin = c0 + c1 in {32, 64, 96, 128}
+  const float* as1; const float* ab1;            // [B][Cin]   GroupNorm-1 affine (ReLU6 follows)
+  const void* w1;                                // [Chid][Cin] T
+  const float* as2; const float* ab2;            // [B][Chid]  GroupNorm-2 + FiLM affine (ReLU6 follows)
+  const float* wd;                               // [9][Chid] fp32 depthwise weights, tap-major
+  void* out; float* pool;
+  int B, H, W, Chid;
+};
+bool dwx_supported(int dtype, int Cin, int Chid, int H, int W);
+hipError_t launch_dwx(int dtype, const DwxArgs& a, hipStream_t s);
 int dwconv_ntiles(int H, int W);
 void dwconv_debug(int v);  // timing ablations (bit 0: no MACs, bit 1: no activation); results are wrong when set
 
