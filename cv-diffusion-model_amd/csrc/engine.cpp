@@ -1111,6 +1111,7 @@ int llie_pw_gemm_tile_rows(int P) { return pw_gemm_tile_rows(P); }
 int llie_tune(const char* knob, int value) {
   if (!knob) return LLIE_ERR_ARG;
   if (!strcmp(knob, "gemm_bk")) { pw_gemm_force_bk(value); return LLIE_OK; }
+  if (!strcmp(knob, "gemm_v2")) { pw_gemm_use_v2(value); return LLIE_OK; }
   if (!strcmp(knob, "dwx")) { g_use_dwx = value != 0; return LLIE_OK; }
   if (!strcmp(knob, "gemm_ablate")) { pw_gemm_debug(value); return LLIE_OK; }
   if (!strcmp(knob, "dw_ablate")) { dwconv_debug(value); return LLIE_OK; }

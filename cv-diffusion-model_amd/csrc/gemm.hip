@@ -299,8 +299,11 @@ static hipError_t launch_t(const GemmArgs& a, hipStream_t s) {
   return launch_cfg<T, 64, 32, 2, 1, 32>(a, s);
 }
 
-static int g_gemm_dbg = 0;
+// g_gemm_v2: the LDS-DMA pipelined variant (gemm2.hip) is numerically equivalent but measured 1.4x slower on
+// MI355X over the layer shapes of small@256, so it is opt-in: llie_tune("gemm_v2", 1).
+static int g_gemm_dbg = 0, g_gemm_v2 = 0;
 void pw_gemm_debug(int v) { g_gemm_dbg = v; }
+void pw_gemm_use_v2(int v) { g_gemm_v2 = v; }
 
 hipError_t launch_pw_gemm(int dtype, const GemmArgs& a0, hipStream_t s) {
   GemmArgs a = a0;
@@ -315,6 +318,7 @@ hipError_t launch_pw_gemm(int dtype, const GemmArgs& a0, hipStream_t s) {
     k += a.seg[i].ch;
   }
   if (k != a.K) return hipErrorInvalidValue;
+  if (g_gemm_v2 && !a.dbg && pw_gemm2_supported(dtype, a)) return launch_pw_gemm2(a, s);
   switch (dtype) {
     case 0: return launch_t<float>(a, s);
     case 1: return launch_t<half_t>(a, s);

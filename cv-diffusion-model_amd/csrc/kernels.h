@@ -49,6 +49,9 @@ struct GemmArgs {
   int dbg;            // timing ablations (set by the launcher from pw_gemm_debug; 0 in production)
 };
 hipError_t launch_pw_gemm(int dtype, const GemmArgs& a, hipStream_t s);
+bool pw_gemm2_supported(int dtype, const GemmArgs& a);   // LDS-DMA pipelined variant (gemm2.hip)
+hipError_t launch_pw_gemm2(const GemmArgs& a, hipStream_t s);
+void pw_gemm_use_v2(int v);
 int pw_gemm_tile_rows(int P);  // BM used for a given P (stats slab tiles = P / BM)
 void pw_gemm_force_bk(int bk);  // tuning knob (0 = automatic)
 void pw_gemm_debug(int v);      // timing ablations; results are wrong when non-zero
