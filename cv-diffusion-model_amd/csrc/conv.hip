@@ -510,19 +510,9 @@ __global__ void __launch_bounds__(WM* WN * 64) conv3x3_kernel(const Conv3Args a)
     }
   }
 
-  // ---- epilogue (same scheme as the pointwise GEMM)
-#pragma unroll
-  for (int i = 0; i < MI; ++i)
-#pragma unroll
-    for (int j = 0; j < NI; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = (wm * MI + i) * 32 + mfma_row(r, lane);
-        const int col = (wn * NI + j) * 32 + (lane & 31);
-        sC[row * CP + col] = acc[i][j][r];
-      }
-  __syncthreads();
-  constexpr int VR = BN / VEC, RPP = NT / VR;
+  // ---- epilogue (same scheme as the pointwise GEMM): one pass per 32-row MFMA block index, so the
+  // fp32 staging tile holds only WM*32 rows and the kernel fits 4 workgroups per CU
+  constexpr int VR = BN / VEC, RPP = NT / VR, SROWS = WM * 32;
   static_assert(NT % VR == 0 && VR <= 64, "epilogue mapping");
   const int cv = tid % VR, r0 = tid / VR;
   float bias[VEC], s1[VEC], s2[VEC];
@@ -533,19 +523,33 @@ __global__ void __launch_bounds__(WM* WN * 64) conv3x3_kernel(const Conv3Args a)
     s2[e] = 0.f;
   }
   T* outp = reinterpret_cast<T*>(a.out) + (size_t)b * Ho * Wo * a.Cout;
-  for (int row = r0; row < BM; row += RPP) {
-    float v[VEC];
-    const float* pc = sC + row * CP + cv * VEC;
 #pragma unroll
-    for (int e = 0; e < VEC; ++e) v[e] = pc[e] + bias[e];
-    const int oy = oy0 + row / TW, ox = ox0 + row % TW;
-    vec_t ov = f32_to_vec<T>(v);
-    st_vec<T>(outp + ((size_t)oy * Wo + ox) * a.Cout + n0 + cv * VEC, ov);
+  for (int pi = 0; pi < MI; ++pi) {
+    if (pi) __syncthreads();
 #pragma unroll
-    for (int e = 0; e < VEC; ++e) {
-      const float q = (float)ov[e];
-      s1[e] += q;
-      s2[e] += q * q;
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = wm * 32 + mfma_row(r, lane);
+        const int col = (wn * NI + j) * 32 + (lane & 31);
+        sC[row * CP + col] = acc[pi][j][r];
+      }
+    __syncthreads();
+    for (int srow = r0; srow < SROWS; srow += RPP) {
+      const int row = ((srow >> 5) * MI + pi) * 32 + (srow & 31);  // pixel index inside the BM tile
+      float v[VEC];
+      const float* pc = sC + srow * CP + cv * VEC;
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) v[e] = pc[e] + bias[e];
+      const int oy = oy0 + row / TW, ox = ox0 + row % TW;
+      vec_t ov = f32_to_vec<T>(v);
+      st_vec<T>(outp + ((size_t)oy * Wo + ox) * a.Cout + n0 + cv * VEC, ov);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        const float q = (float)ov[e];
+        s1[e] += q;
+        s2[e] += q * q;
+      }
     }
   }
   if (a.stats) {
@@ -556,7 +560,7 @@ __global__ void __launch_bounds__(WM* WN * 64) conv3x3_kernel(const Conv3Args a)
         s1[e] += __shfl_xor(s1[e], o, 64);
         s2[e] += __shfl_xor(s2[e], o, 64);
       }
-    float* red = sC + BM * CP;
+    float* red = sC + SROWS * CP;
     constexpr int NW = NT / 64;
     if (lane < VR) {
 #pragma unroll
@@ -584,7 +588,7 @@ static hipError_t launch_conv_cfg(const Conv3Args& a, hipStream_t s) {
   constexpr int NT = WM * WN * 64, BM = 8 * TW, PITCH = TilePitch<T>::value;
   constexpr int PH = MODE == 0 ? 17 : 10, PW = MODE == 0 ? 2 * TW + 1 : TW + 2;
   constexpr size_t tiles = (size_t)(PH * PW + BN) * PITCH * sizeof(T);
-  constexpr size_t ctile = (size_t)BM * (BN + 4) * 4 + (size_t)(NT / 64) * 2 * BN * 4;
+  constexpr size_t ctile = (size_t)(WM * 32) * (BN + 4) * 4 + (size_t)(NT / 64) * 2 * BN * 4;
   constexpr size_t lds = tiles > ctile ? tiles : ctile;
   static bool attr_done = false;
   if (!attr_done && lds > 48 * 1024) {

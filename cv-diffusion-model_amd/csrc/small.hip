@@ -29,12 +29,24 @@ __global__ void __launch_bounds__(256) gn_finalize_kernel(const GnFinalizeArgs a
     // channels of this group that live in this source: [lo, hi) in source-local numbering
     const int lo = max(c_lo - coff, 0), hi = min(c_lo + cg - coff, src.ch);
     if (hi > lo) {
-      const int w = hi - lo, total = w * src.ntiles;
-      const float* base = src.slab + (size_t)b * src.ntiles * 2 * src.ch;
-      for (int i = tid; i < total; i += 256) {
-        const int t = i / w, c = lo + i % w;
-        s1 += (double)base[(size_t)(t * 2 + 0) * src.ch + c];
-        s2 += (double)base[(size_t)(t * 2 + 1) * src.ch + c];
+      // thread -> (tile lane tl, channel c): consecutive threads read consecutive channels of one
+      // tile row (coalesced), then stride over tiles; no division inside the loop
+      const int w = hi - lo;
+      const int per = w <= 256 ? 256 / w : 1;       // tiles covered per sweep of the block
+      const int tl = w <= 256 ? tid / w : 0, cc = w <= 256 ? tid % w : tid;
+      const float* base = src.slab + (size_t)b * src.ntiles * 2 * src.ch + lo;
+      if (w <= 256) {
+        if (tl < per)
+          for (int t = tl; t < src.ntiles; t += per) {
+            s1 += (double)base[(size_t)(t * 2 + 0) * src.ch + cc];
+            s2 += (double)base[(size_t)(t * 2 + 1) * src.ch + cc];
+          }
+      } else {
+        for (int t = 0; t < src.ntiles; ++t)
+          for (int c = tid; c < w; c += 256) {
+            s1 += (double)base[(size_t)(t * 2 + 0) * src.ch + c];
+            s2 += (double)base[(size_t)(t * 2 + 1) * src.ch + c];
+          }
       }
     }
     coff += src.ch;

@@ -80,8 +80,8 @@ def resolve_compute_dtype(explicit: Optional[str]) -> int:
     the matching fp16/bf16 engine."""
     if explicit is not None:
         return N.dtype_code(explicit)
-    if torch.is_autocast_enabled():
-        return N.dtype_code(torch.get_autocast_gpu_dtype())
+    if torch.is_autocast_enabled("cuda"):
+        return N.dtype_code(torch.get_autocast_dtype("cuda"))
     return N.LLIE_F32
 
 
