@@ -291,9 +291,17 @@ __global__ void __launch_bounds__(256) final_conv_mfma_kernel(const FinalConvArg
 
   for (int cc = 0; cc < a.C; cc += 32) {
     if (cc) __syncthreads();
-    // stage the activated 18x18x32 patch (GroupNorm affine + SiLU applied once per element)
+    // stage the activated 18x18x32 patch (GroupNorm affine + SiLU applied once per element); a thread's
+    // 8-channel slice is loop invariant (256 % 4 == 0), so its affine pairs live in registers
+    const int cv = (tid & 3) * 8;
+    float sc[8], sh[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      sc[e] = a.as[(size_t)b * a.C + cc + cv + e];
+      sh[e] = a.ab[(size_t)b * a.C + cc + cv + e];
+    }
     for (int i = tid; i < (18 * PWD + 1) * 4; i += 256) {
-      const int pix = i >> 2, cv = (i & 3) * 8;
+      const int pix = i >> 2;
       const int ppy = pix / PWD, ppx = pix % PWD;
       const int gy = y0 + ppy - 1, gx = x0 + ppx - 1;
       vec_t v = zero;
@@ -301,10 +309,7 @@ __global__ void __launch_bounds__(256) final_conv_mfma_kernel(const FinalConvArg
         float f[8];
         ld_f32<T>(in + ((size_t)gy * a.W + gx) * a.C + cc + cv, f);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const int c = cc + cv + e;
-          f[e] = siluf(f[e] * a.as[(size_t)b * a.C + c] + a.ab[(size_t)b * a.C + c]);
-        }
+        for (int e = 0; e < 8; ++e) f[e] = siluf(f[e] * sc[e] + sh[e]);
         v = f32_to_vec<T>(f);
       }
       *reinterpret_cast<vec_t*>(patch + pix * PIX + cv) = v;
