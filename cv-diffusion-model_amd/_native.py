@@ -23,7 +23,7 @@ EXPORTS = [
     "llie_load_param", "llie_params_loaded", "llie_workspace_bytes", "llie_unet_forward", "llie_module_forward",
     "llie_lcm_step", "llie_add_noise", "llie_enhance", "llie_algorithmic_bytes", "llie_flops",
     "llie_profile_begin", "llie_profile_end", "llie_enhance_workspace_bytes",
-    "llie_profile_report", "llie_pw_gemm", "llie_pw_gemm_tile_rows", "llie_dwconv3x3", "llie_dwconv3x3_tiles", "llie_tune",
+    "llie_preprocess_u8", "llie_postprocess_u8", "llie_profile_report", "llie_pw_gemm", "llie_pw_gemm_tile_rows", "llie_dwconv3x3", "llie_dwconv3x3_tiles", "llie_tune",
 ]
 K_GEMM, K_DW, K_CONV3, K_SE = 1, 2, 4, 8
 
@@ -91,6 +91,8 @@ def lib() -> C.CDLL:
     L.llie_algorithmic_bytes.restype = i64
     L.llie_flops.argtypes = [vp, ci]
     L.llie_flops.restype = i64
+    L.llie_preprocess_u8.argtypes = [vp, ci, ci, ci, vp, ci, vp]
+    L.llie_postprocess_u8.argtypes = [vp, ci, ci, vp, ci, ci, vp]
     L.llie_pw_gemm.argtypes = [ci, C.POINTER(GemmSeg), ci, vp, vp, vp, vp, vp, ci, ci, ci, vp]
     L.llie_pw_gemm_tile_rows.argtypes = [ci]
     L.llie_dwconv3x3.argtypes = [ci, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, vp]

@@ -335,6 +335,8 @@ __global__ void __launch_bounds__(256) final_conv_mfma_kernel(const FinalConvArg
   }
   if (h) return;  // rows 4..7 of D (lane half 1) are padding
   const size_t plane = (size_t)a.H * a.W;
+  {
+#pragma clang fp contract(off)  // scheduler step: keep the reference's operation order (no fused multiply-adds)
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
     const int g = wave * 2 + t;
@@ -348,14 +350,15 @@ __global__ void __launch_bounds__(256) final_conv_mfma_kernel(const FinalConvArg
       if (a.fuse_step) {
         const float xv = a.sample[idx];
         float x0v;
-        if (a.coef.vpred) x0v = __fsub_rn(__fmul_rn(a.coef.sa, xv), __fmul_rn(a.coef.sb, e));
-        else x0v = __fdiv_rn(__fsub_rn(xv, __fmul_rn(a.coef.sb, e)), a.coef.sa);
+        if (a.coef.vpred) x0v = a.coef.sa * xv - a.coef.sb * e;
+        else x0v = (xv - a.coef.sb * e) / a.coef.sa;
         float pv = x0v;
-        if (!a.coef.is_last) pv = __fadd_rn(__fmul_rn(a.coef.sap, x0v), __fmul_rn(a.coef.sbp, a.noise[idx]));
+        if (!a.coef.is_last) pv = a.coef.sap * x0v + a.coef.sbp * a.noise[idx];
         a.prev[idx] = pv;
         if (a.clamped) a.clamped[idx] = fminf(fmaxf(pv, -1.f), 1.f);
       }
     }
+  }
   }
 }
 hipError_t launch_final_conv(int dtype, const FinalConvArgs& a, hipStream_t s) {

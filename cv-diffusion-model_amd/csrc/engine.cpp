@@ -1105,6 +1105,21 @@ int llie_dwconv3x3(int dtype, const void* in, void* out, const float* scale, con
   return LLIE_OK;
 }
 
+int llie_preprocess_u8(const uint8_t* img, int batch, int H0, int W0, float* out, int S, llie_stream stream) {
+  if (!img || !out) return LLIE_ERR_ARG;
+  hipError_t e = launch_preprocess_u8(img, batch, H0, W0, out, S, reinterpret_cast<hipStream_t>(stream));
+  if (e == hipErrorInvalidValue) return LLIE_ERR_ARG;
+  if (e != hipSuccess) { set_err("preprocess_u8: %s", hipGetErrorString(e)); return (int)e; }
+  return LLIE_OK;
+}
+int llie_postprocess_u8(const float* x, int batch, int S, uint8_t* img, int H0, int W0, llie_stream stream) {
+  if (!img || !x) return LLIE_ERR_ARG;
+  hipError_t e = launch_postprocess_u8(x, batch, S, img, H0, W0, reinterpret_cast<hipStream_t>(stream));
+  if (e == hipErrorInvalidValue) return LLIE_ERR_ARG;
+  if (e != hipSuccess) { set_err("postprocess_u8: %s", hipGetErrorString(e)); return (int)e; }
+  return LLIE_OK;
+}
+
 int llie_dwconv3x3_tiles(int H, int W) { return dwconv_ntiles(H, W); }
 int llie_pw_gemm_tile_rows(int P) { return pw_gemm_tile_rows(P); }
 

@@ -212,6 +212,10 @@ hipError_t launch_repack_final(const float* src, float* dst, int O, int I, hipSt
 hipError_t launch_repack_final_mfma(int dtype, const float* src, void* dst, int O, int I, hipStream_t s);    // OIHW -> [I/32][18][2][4][8] T
 hipError_t launch_repack_init_mfma(int dtype, const float* src, void* dst, int O, int I, hipStream_t s);     // OIHW -> [5][2][O][8] T
 
+// uint8 HWC RGB <-> normalised fp32 NCHW with bilinear resize (scripts/inference.py:99-134), bit-exact with hostio.py.
+hipError_t launch_preprocess_u8(const uint8_t* img, int B, int H0, int W0, float* out, int S, hipStream_t s);
+hipError_t launch_postprocess_u8(const float* x, int B, int S, uint8_t* img, int H0, int W0, hipStream_t s);
+
 // LCM scheduler elementwise ops (fp32).
 hipError_t launch_lcm_step(const float* eps, const float* x, const float* noise, float* prev, float* x0,
                            float* clamped, int64_t n, StepCoef c, hipStream_t s);

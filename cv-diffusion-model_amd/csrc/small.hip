@@ -652,18 +652,106 @@ hipError_t launch_repack_final(const float* src, float* dst, int O, int I, hipSt
 }
 
 // =============================================================================================
+// uint8 image I/O either side of the path (scripts/inference.py:99-134), bit-exact with the host
+// implementation (hostio.py): bilinear resize with cv2.INTER_LINEAR's half-pixel geometry evaluated in
+// fp32 WITHOUT fused multiply-adds (NumPy evaluates a*(1-f) + b*f as two products and a sum), rounding
+// half up to uint8; then x/127.5 - 1 on the way in, (x+1)*127.5 clipped and truncated on the way out.
+struct ResizeAxis { int i0, i1; float f; };
+// NB: HIP's __fmul_rn / __fadd_rn are ordinary operators, so clang's default -ffp-contract=fast would
+// still fuse them; contraction is switched off per function where the operation order is part of the contract.
+__device__ __forceinline__ ResizeAxis resize_axis(int o, int n_in, float scale) {
+#pragma clang fp contract(off)
+  const float pos = ((float)o + 0.5f) * scale - 0.5f;
+  const float fl = floorf(pos);
+  ResizeAxis r;
+  const int lo = (int)fl;
+  r.f = pos - fl;
+  r.i0 = min(max(lo, 0), n_in - 1);
+  r.i1 = min(max(lo + 1, 0), n_in - 1);
+  return r;
+}
+__device__ __forceinline__ float lerp2_nofma(float v00, float v01, float v10, float v11, float fx, float fy) {
+#pragma clang fp contract(off)
+  const float gx = 1.f - fx, gy = 1.f - fy;
+  const float top = v00 * gx + v01 * fx;
+  const float bot = v10 * gx + v11 * fx;
+  return top * gy + bot * fy;
+}
+__device__ __forceinline__ float round_u8(float v) {
+#pragma clang fp contract(off)
+  return fminf(fmaxf(floorf(v + 0.5f), 0.f), 255.f);
+}
+
+// img u8 [B][H0][W0][3] -> out fp32 [B][3][S][S]
+__global__ void preprocess_u8_kernel(const uint8_t* img, int H0, int W0, float* out, int S, float sy, float sx) {
+#pragma clang fp contract(off)
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y, b = blockIdx.z;
+  if (x >= S) return;
+  const uint8_t* src = img + (size_t)b * H0 * W0 * 3;
+  float u[3];
+  if (H0 == S && W0 == S) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) u[c] = (float)src[((size_t)y * W0 + x) * 3 + c];
+  } else {
+    const ResizeAxis ay = resize_axis(y, H0, sy), ax = resize_axis(x, W0, sx);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float v = lerp2_nofma((float)src[((size_t)ay.i0 * W0 + ax.i0) * 3 + c], (float)src[((size_t)ay.i0 * W0 + ax.i1) * 3 + c],
+                                  (float)src[((size_t)ay.i1 * W0 + ax.i0) * 3 + c], (float)src[((size_t)ay.i1 * W0 + ax.i1) * 3 + c], ax.f, ay.f);
+      u[c] = round_u8(v);
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < 3; ++c) out[(((size_t)b * 3 + c) * S + y) * S + x] = u[c] / 127.5f - 1.0f;
+}
+// x fp32 [B][3][S][S] -> img u8 [B][H0][W0][3]
+__global__ void postprocess_u8_kernel(const float* xin, int S, uint8_t* img, int H0, int W0, float sy, float sx) {
+#pragma clang fp contract(off)
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y, b = blockIdx.z;
+  if (x >= W0) return;
+  const float* src = xin + (size_t)b * 3 * S * S;
+  auto den = [&](int c, int yy, int xx) {  // (x+1)*127.5, clip, truncate -> the uint8 the host would have stored
+    const float v = (src[((size_t)c * S + yy) * S + xx] + 1.0f) * 127.5f;
+    return truncf(fminf(fmaxf(v, 0.f), 255.f));
+  };
+  uint8_t* dst = img + (((size_t)b * H0 + y) * W0 + x) * 3;
+  if (H0 == S && W0 == S) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) dst[c] = (uint8_t)den(c, y, x);
+  } else {
+    const ResizeAxis ay = resize_axis(y, S, sy), ax = resize_axis(x, S, sx);
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+      dst[c] = (uint8_t)round_u8(lerp2_nofma(den(c, ay.i0, ax.i0), den(c, ay.i0, ax.i1), den(c, ay.i1, ax.i0), den(c, ay.i1, ax.i1), ax.f, ay.f));
+  }
+}
+hipError_t launch_preprocess_u8(const uint8_t* img, int B, int H0, int W0, float* out, int S, hipStream_t s) {
+  if (B <= 0 || H0 <= 0 || W0 <= 0 || S <= 0) return hipErrorInvalidValue;
+  const float sy = (float)((double)H0 / (double)S), sx = (float)((double)W0 / (double)S);
+  hipLaunchKernelGGL(preprocess_u8_kernel, dim3((S + 127) / 128, S, B), dim3(128), 0, s, img, H0, W0, out, S, sy, sx);
+  return hipGetLastError();
+}
+hipError_t launch_postprocess_u8(const float* x, int B, int S, uint8_t* img, int H0, int W0, hipStream_t s) {
+  if (B <= 0 || H0 <= 0 || W0 <= 0 || S <= 0) return hipErrorInvalidValue;
+  const float sy = (float)((double)S / (double)H0), sx = (float)((double)S / (double)W0);
+  hipLaunchKernelGGL(postprocess_u8_kernel, dim3((W0 + 127) / 128, H0, B), dim3(128), 0, s, x, S, img, H0, W0, sy, sx);
+  return hipGetLastError();
+}
+
+// =============================================================================================
 // LCMScheduler.step (lcm_scheduler.py:204-242), same operation order as the reference:
 //   x0 = (x - sb*eps)/sa  |  x0 = sa*x - sb*v ;  prev = last ? x0 : sap*x0 + sbp*noise
 __global__ void lcm_step_kernel(const float* eps, const float* x, const float* noise, float* prev, float* x0o,
                                 float* clamped, int64_t n, StepCoef c) {
+#pragma clang fp contract(off)
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const float e = eps[i], xv = x[i];
   float x0;
-  if (c.vpred) x0 = __fsub_rn(__fmul_rn(c.sa, xv), __fmul_rn(c.sb, e));
-  else x0 = __fdiv_rn(__fsub_rn(xv, __fmul_rn(c.sb, e)), c.sa);
+  if (c.vpred) x0 = c.sa * xv - c.sb * e;
+  else x0 = (xv - c.sb * e) / c.sa;
   float p = x0;
-  if (!c.is_last) p = __fadd_rn(__fmul_rn(c.sap, x0), __fmul_rn(c.sbp, noise[i]));
+  if (!c.is_last) p = c.sap * x0 + c.sbp * noise[i];
   prev[i] = p;
   if (x0o) x0o[i] = x0;
   if (clamped) clamped[i] = fminf(fmaxf(p, -1.f), 1.f);
@@ -678,14 +766,14 @@ hipError_t launch_lcm_step(const float* eps, const float* x, const float* noise,
 // add_noise / get_velocity (lcm_scheduler.py:255-305)
 __global__ void add_noise_kernel(const float* x0, const float* noise, const int64_t* t, const float* acp, float* out,
                                  int64_t per, int velocity) {
+#pragma clang fp contract(off)
   const int b = blockIdx.y;
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= per) return;
   const float a = acp[t[b]];
   const float sa = sqrtf(a), sb = sqrtf(1.f - a);
   const size_t o = (size_t)b * per + i;
-  out[o] = velocity ? __fsub_rn(__fmul_rn(sa, noise[o]), __fmul_rn(sb, x0[o]))
-                    : __fadd_rn(__fmul_rn(sa, x0[o]), __fmul_rn(sb, noise[o]));
+  out[o] = velocity ? sa * noise[o] - sb * x0[o] : sa * x0[o] + sb * noise[o];
 }
 hipError_t launch_add_noise(const float* x0, const float* noise, const int64_t* t, const float* acp, float* out, int B,
                             int64_t per, int velocity, hipStream_t s) {

@@ -78,6 +78,41 @@ def postprocess_array(output: np.ndarray, original_size: Tuple[int, int]) -> np.
     return resize_bilinear(out, original_size[0], original_size[1])
 
 
+def preprocess_device(rgb_u8: torch.Tensor, target_size: int) -> torch.Tensor:
+    """Device twin of preprocess_array: uint8 [B,H,W,3] (or [H,W,3]) on a HIP device -> fp32 [B,3,S,S] in
+    [-1,1], resized and normalised by libllie_hip.so; bit-exact with the host path."""
+    from . import _native as N
+    if rgb_u8.device.type != "cuda" or rgb_u8.dtype != torch.uint8:
+        raise RuntimeError("preprocess_device expects a uint8 tensor on a HIP device")
+    x = rgb_u8 if rgb_u8.dim() == 4 else rgb_u8.unsqueeze(0)
+    x = x.contiguous()
+    b, h, w, c = x.shape
+    if c != 3:
+        raise ValueError("expected RGB images, [.., H, W, 3]")
+    out = torch.empty(b, 3, target_size, target_size, dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        N.check(N.lib().llie_preprocess_u8(x.data_ptr(), b, h, w, out.data_ptr(), target_size,
+                                           torch.cuda.current_stream(x.device).cuda_stream), "preprocess_u8")
+    return out
+
+
+def postprocess_device(output: torch.Tensor, original_size: Tuple[int, int]) -> torch.Tensor:
+    """Device twin of postprocess_array: fp32 [B,3,S,S] -> uint8 [B,H0,W0,3]; bit-exact with the host path."""
+    from . import _native as N
+    if output.device.type != "cuda":
+        raise RuntimeError("postprocess_device expects a tensor on a HIP device")
+    x = output.detach().float().contiguous()
+    b, c, s, s2 = x.shape
+    if c != 3 or s != s2:
+        raise ValueError("expected [B,3,S,S]")
+    h0, w0 = original_size
+    img = torch.empty(b, h0, w0, 3, dtype=torch.uint8, device=x.device)
+    with torch.cuda.device(x.device):
+        N.check(N.lib().llie_postprocess_u8(x.data_ptr(), b, s, img.data_ptr(), h0, w0,
+                                            torch.cuda.current_stream(x.device).cuda_stream), "postprocess_u8")
+    return img
+
+
 def load_image(path: str) -> np.ndarray:
     from PIL import Image
     return np.asarray(Image.open(path).convert("RGB"))

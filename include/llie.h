@@ -148,6 +148,15 @@ int llie_enhance(llie_ctx* ctx, const float* low_light, const float* noise, cons
                  const llie_step_coef* coefs, int steps, float* enhanced, float* intermediates,
                  float* noise_preds, int batch, void* workspace, int64_t workspace_bytes, llie_stream stream);
 
+/* Byte-level I/O either side of the path (scripts/inference.py:99-134), on the device:
+ *   llie_preprocess_u8:  uint8 HWC RGB [B][H0][W0][3] -> resize to SxS (cv2.INTER_LINEAR geometry, round half
+ *                        up to uint8) -> x/127.5 - 1 -> fp32 NCHW [B][3][S][S]
+ *   llie_postprocess_u8: fp32 NCHW [B][3][S][S] -> (x+1)*127.5, clip [0,255], truncate to uint8 -> resize to
+ *                        H0xW0 -> uint8 HWC RGB [B][H0][W0][3]
+ * Bit-exact with the host implementation in hostio.py (fp32 arithmetic without fused multiply-adds). */
+int llie_preprocess_u8(const uint8_t* img, int batch, int H0, int W0, float* out, int S, llie_stream stream);
+int llie_postprocess_u8(const float* x, int batch, int S, uint8_t* img, int H0, int W0, llie_stream stream);
+
 /* ---- Kernel-level entry points (unit tests and tuning; SURVEY.md 8b "per-kernel entry points").
  * Activations are NHWC rows in the compute dtype T (llie_dtype); see DESIGN.md section 3.
  *

@@ -46,13 +46,17 @@ def load_model(args):
 
 def process_single_image(args, model, input_path: str, output_path: str) -> float:
     print(f"Processing: {input_path}")
-    image, original = hostio.preprocess_array(hostio.load_image(input_path), args.image_size)
+    rgb = hostio.load_image(input_path)
+    original = rgb.shape[:2]
     start = time.perf_counter()
     with torch.no_grad():
-        enhanced = model.enhance(torch.from_numpy(image).to(args.device), num_inference_steps=args.num_steps)
-    enhanced = enhanced.cpu().numpy()
+        # uint8 goes up, uint8 comes back: resize + normalise / denormalise run on the device
+        # (bit-exact twins of hostio.preprocess_array / postprocess_array, i.e. inference.py:99-134)
+        x = hostio.preprocess_device(torch.from_numpy(rgb).to(args.device), args.image_size)
+        enhanced = model.enhance(x, num_inference_steps=args.num_steps)
+        out = hostio.postprocess_device(enhanced, original)[0].cpu().numpy()
     elapsed = time.perf_counter() - start
-    hostio.save_image(output_path, hostio.postprocess_array(enhanced, original))
+    hostio.save_image(output_path, out)
     print(f"  Saved to: {output_path}")
     print(f"  Time: {elapsed * 1000:.1f} ms")
     return elapsed

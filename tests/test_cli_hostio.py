@@ -71,6 +71,22 @@ def test_cli_flags_match_reference():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("shape,size", [((37, 53), 64), ((200, 120), 64), ((64, 64), 64), ((300, 400), 128)])
+def test_device_pre_post_processing_bit_exact(shape, size):
+    """llie_preprocess_u8 / llie_postprocess_u8 vs the host implementation: byte work, so bit-exact."""
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(5)
+    imgs = rng.integers(0, 256, size=(2,) + shape + (3,), dtype=np.uint8)
+    ref = np.concatenate([M.preprocess_array(im, size)[0] for im in imgs])
+    got = M.preprocess_device(torch.from_numpy(imgs).to(dev), size).cpu().numpy()
+    assert got.dtype == np.float32 and np.array_equal(got, ref)
+    x = (rng.random((2, 3, size, size), dtype=np.float32) * 2.6 - 1.3)  # includes out-of-range values to clip
+    refp = np.stack([M.postprocess_array(x[i:i + 1], shape) for i in range(2)])
+    gotp = M.postprocess_device(torch.from_numpy(x).to(dev), shape).cpu().numpy()
+    assert gotp.dtype == np.uint8 and np.array_equal(gotp, refp)
+
+
+@pytest.mark.gpu
 def test_cli_end_to_end(tmp_path):
     from PIL import Image
     spec = oracle.make_spec("small", 64)
