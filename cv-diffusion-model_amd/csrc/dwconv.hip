@@ -15,11 +15,21 @@
 // LDS per workgroup is ~9 KB, so occupancy is set by registers, not LDS; halo re-reads are 2 rows per
 // TYL and 2 columns per TX.
 #include <string>
+#include <type_traits>
 
 #include "common.h"
 #include "kernels.h"
 
 namespace llie {
+
+// acc += w * f with w and f taken as the LOW (HI = 0) or HIGH (HI = 1) f16 half of two packed registers and
+// an fp32 accumulator: one v_fma_mix_f32, no separate conversions (the compiler otherwise emits a
+// v_cvt_f32_f16 per operand use -- ~100 extra VALU instructions per row of this kernel).
+template <int HI>
+__device__ __forceinline__ void fma_mix_f16(float& acc, uint32_t w2, uint32_t f2) {
+  if (HI) asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,1,0]" : "+v"(acc) : "v"(w2), "v"(f2));
+  else asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,1,0]" : "+v"(acc) : "v"(w2), "v"(f2));
+}
 
 constexpr int kDwPF = 4;  // rows of global loads kept in flight per thread
 
@@ -85,59 +95,68 @@ __global__ void __launch_bounds__(8 * TX) dwconv3x3_kernel(const DwArgs a, const
 #pragma unroll
   for (int j = 0; j < PF; ++j) issue(j, pre[j], preh[j]);
 
-  float acc0[VEC], acc1[VEC], acc2[VEC], psum[VEC];
+  // acc[o % 3] accumulates output row o.  The row loop is unrolled 12-fold (lcm of the prefetch depth 4
+  // and the 3 accumulator roles) so that accumulator indices, prefetch slots and the ring buffer parity
+  // are all compile-time constants: no per-row register rotation.
+  float acc[3][VEC], psum[VEC];
 #pragma unroll
-  for (int e = 0; e < VEC; ++e) acc0[e] = acc1[e] = acc2[e] = psum[e] = 0.f;
+  for (int e = 0; e < VEC; ++e) acc[0][e] = acc[1][e] = acc[2][e] = psum[e] = 0.f;
 
-  for (int r0 = 0; r0 < nrows; r0 += PF) {
+  static_assert(PF == 4, "the 12-row unroll below assumes 4 prefetch slots");
+  for (int r0 = 0; r0 < nrows; r0 += 12) {
 #pragma unroll
-    for (int j = 0; j < PF; ++j) {
+    for (int j = 0; j < 12; ++j) {
       const int r = r0 + j;
       if (r >= nrows) break;  // uniform over the workgroup
       const int gy = y0 - 1 + r;
       const bool row_ok = gy >= 0 && gy < a.H;
-      vec_t* buf = ring[j & 1];  // PF is even, so r & 1 == j & 1
-      buf[(xl + 1) * 8 + cl] = row_ok ? ((dbg & 2) ? pre[j] : activate(pre[j])) : zero;
-      if (is_halo) buf[hslot * 8 + cl] = (row_ok && hx_ok) ? activate(preh[j]) : zero;
-      issue(r + PF, pre[j], preh[j]);
+      vec_t* buf = ring[j & 1];  // r0 is a multiple of 12, so r & 1 == j & 1, r % 4 == j % 4, r % 3 == j % 3
+      buf[(xl + 1) * 8 + cl] = row_ok ? ((dbg & 2) ? pre[j % 4] : activate(pre[j % 4])) : zero;
+      if (is_halo) buf[hslot * 8 + cl] = (row_ok && hx_ok) ? activate(preh[j % 4]) : zero;
+      issue(r + PF, pre[j % 4], preh[j % 4]);
       __syncthreads();
       vec_t f[3];
 #pragma unroll
       for (int kx = 0; kx < 3; ++kx) f[kx] = buf[(xl + kx) * 8 + cl];
-      // Opaque touch of the packed weights inside the loop: stops LICM from hoisting their
-      // T->f32 conversion (72 VGPRs for 2-byte T), so the products below select v_fma_mix_f32.
-      if (sizeof(T) == 2) {
-#pragma unroll
-        for (int t = 0; t < 9; ++t) {
-          u32x4& q = reinterpret_cast<u32x4&>(w[t]);
-          asm volatile("" : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]));
-        }
-      }
+      float* a2 = acc[(j + 1) % 3];  // ky = 2 -> output row r-2
+      float* a1 = acc[(j + 2) % 3];  // ky = 1 -> output row r-1
+      float* a0 = acc[j % 3];        // ky = 0 -> output row r
       if (dbg & 1) {  // ablation: no multiply-accumulate (timing experiments only)
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) acc0[e] += (float)f[1][e];
+        for (int e = 0; e < VEC; ++e) a2[e] += (float)f[1][e];
+      } else if constexpr (std::is_same<T, half_t>::value) {
+        // fp16: weights and data stay packed; 72 v_fma_mix_f32 per row
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          const u32x4 fq = reinterpret_cast<const u32x4&>(f[kx]);
+          const u32x4 w2 = reinterpret_cast<const u32x4&>(w[6 + kx]);
+          const u32x4 w1 = reinterpret_cast<const u32x4&>(w[3 + kx]);
+          const u32x4 w0 = reinterpret_cast<const u32x4&>(w[0 + kx]);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            fma_mix_f16<0>(a2[2 * q], w2[q], fq[q]); fma_mix_f16<1>(a2[2 * q + 1], w2[q], fq[q]);
+            fma_mix_f16<0>(a1[2 * q], w1[q], fq[q]); fma_mix_f16<1>(a1[2 * q + 1], w1[q], fq[q]);
+            fma_mix_f16<0>(a0[2 * q], w0[q], fq[q]); fma_mix_f16<1>(a0[2 * q + 1], w0[q], fq[q]);
+          }
+        }
       } else {
 #pragma unroll
-      for (int kx = 0; kx < 3; ++kx)
+        for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) {
-          acc0[e] += (float)w[6 + kx][e] * (float)f[kx][e];  // ky = 2 -> output row r-2
-          acc1[e] += (float)w[3 + kx][e] * (float)f[kx][e];  // ky = 1 -> output row r-1
-          acc2[e] += (float)w[0 + kx][e] * (float)f[kx][e];  // ky = 0 -> output row r
-        }
+          for (int e = 0; e < VEC; ++e) {
+            a2[e] += (float)w[6 + kx][e] * (float)f[kx][e];
+            a1[e] += (float)w[3 + kx][e] * (float)f[kx][e];
+            a0[e] += (float)w[0 + kx][e] * (float)f[kx][e];
+          }
       }
       if (r >= 2) {
-        vec_t ov = f32_to_vec<T>(acc0);
+        vec_t ov = f32_to_vec<T>(a2);
         st_vec<T>(out + ((size_t)(y0 + r - 2) * a.W + x0 + xl) * a.C, ov);
 #pragma unroll
         for (int e = 0; e < VEC; ++e) psum[e] += (float)ov[e];
       }
 #pragma unroll
-      for (int e = 0; e < VEC; ++e) {
-        acc0[e] = acc1[e];
-        acc1[e] = acc2[e];
-        acc2[e] = 0.f;
-      }
+      for (int e = 0; e < VEC; ++e) a2[e] = 0.f;  // slot becomes the accumulator of output row r+1
     }
   }
   // ---- SE pool partial: sum over the strip's pixels per channel (fixed order)
