@@ -87,6 +87,52 @@ __device__ __forceinline__ double wave_sum(double v) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// SE average-pool partials of the depthwise kernels.  A partial always covers one 8-row segment of a
+// strip (whatever the strip height of the launch), so the pooled mean of an image is the same bits
+// for every batch size.  Thread layout: lane = 8 * (pixel & 7) + cl, each thread holding VEC channel
+// sums of its pixel.  A transposed butterfly over lane bits 3..5 leaves every lane with one channel's
+// sum over the wave's 8 pixels (7 shuffles for VEC = 8 instead of 24).
+constexpr int kPoolSegRows = 8;
+template <int VEC>
+__device__ __forceinline__ void pool_segment_flush(float (&psum)[VEC], float* red_wave /* [8 * VEC] */, int lane) {
+  static_assert(VEC == 8 || VEC == 4, "");
+  const bool h1 = lane & 8, h2 = lane & 16, h3 = lane & 32;
+  const int cl = lane & 7;
+  if constexpr (VEC == 8) {
+    float v4[4], v2[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v4[i] = (h1 ? psum[4 + i] : psum[i]) + __shfl_xor(h1 ? psum[i] : psum[4 + i], 8, 64);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) v2[i] = (h2 ? v4[2 + i] : v4[i]) + __shfl_xor(h2 ? v4[i] : v4[2 + i], 16, 64);
+    const float v1 = (h3 ? v2[1] : v2[0]) + __shfl_xor(h3 ? v2[0] : v2[1], 32, 64);
+    red_wave[cl * 8 + (h1 ? 4 : 0) + (h2 ? 2 : 0) + (h3 ? 1 : 0)] = v1;
+  } else {
+    float v2[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) v2[i] = (h1 ? psum[2 + i] : psum[i]) + __shfl_xor(h1 ? psum[i] : psum[2 + i], 8, 64);
+    float v1 = (h2 ? v2[1] : v2[0]) + __shfl_xor(h2 ? v2[0] : v2[1], 16, 64);
+    v1 += __shfl_xor(v1, 32, 64);
+    if (!h3) red_wave[cl * 4 + (h1 ? 2 : 0) + (h2 ? 1 : 0)] = v1;
+  }
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) psum[e] = 0.f;
+}
+// After the strip: combine the waves of every segment in wave order and write the slab entries
+//   pool[b][(seg_y * tiles_x + tx)][c],  seg_y = global 8-row segment index.  red = [nseg][NW][CC].
+template <int CC, int NT>
+__device__ __forceinline__ void pool_segments_store(const float* red, int nseg, int tid, float* pool_img /* + b*ntiles*C + cbase */,
+                                                    int C, int seg_y0, int tiles_x, int tx) {
+  constexpr int NW = NT / 64;
+  for (int i = tid; i < nseg * CC; i += NT) {
+    const int seg = i / CC, c = i % CC;
+    float t = 0.f;
+#pragma unroll
+    for (int wv = 0; wv < NW; ++wv) t += red[(seg * NW + wv) * CC + c];
+    pool_img[((size_t)(seg_y0 + seg) * tiles_x + tx) * C + c] = t;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // MFMA wrappers.  One k-chunk = 32 K-values; lane half h = lane>>5 owns k in [16h, 16h+16) of the
 // chunk for BOTH operands (any k permutation is legal as long as A and B agree), so each lane reads
 // 16 contiguous elements of its row per chunk.

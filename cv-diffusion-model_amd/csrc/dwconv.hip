@@ -42,7 +42,7 @@ __global__ void __launch_bounds__(8 * TX) dwconv3x3_kernel(const DwArgs a, const
   constexpr int PF = PFV;
   typedef typename Elem<T>::vec_t vec_t;
   __shared__ vec_t ring[2][PW * 8];
-  __shared__ float red[(NT / 64) * CC];
+  __shared__ float red[8 * (NT / 64) * CC];  // [8-row segment of the strip][wave][channel]
 
   const int tid = threadIdx.x, cl = tid & 7, xl = tid >> 3;
   const int tiles_x = a.W / TX;
@@ -154,44 +154,42 @@ __global__ void __launch_bounds__(8 * TX) dwconv3x3_kernel(const DwArgs a, const
         st_vec<T>(out + ((size_t)(y0 + r - 2) * a.W + x0 + xl) * a.C, ov);
 #pragma unroll
         for (int e = 0; e < VEC; ++e) psum[e] += (float)ov[e];
+        if (a.pool && ((r - 2) & 7) == 7)  // uniform: an 8-row pool segment is complete
+          pool_segment_flush<VEC>(psum, red + (((r - 2) >> 3) * (NT / 64) + (tid >> 6)) * CC, tid & 63);
       }
 #pragma unroll
       for (int e = 0; e < VEC; ++e) a2[e] = 0.f;  // slot becomes the accumulator of output row r+1
     }
   }
-  // ---- SE pool partial: sum over the strip's pixels per channel (fixed order)
+  // ---- SE pool partials, one per 8-row segment (layout independent of the strip height)
   if (a.pool) {
-#pragma unroll
-    for (int o = 8; o < 64; o <<= 1)
-#pragma unroll
-      for (int e = 0; e < VEC; ++e) psum[e] += __shfl_xor(psum[e], o, 64);
-    const int lane = tid & 63, wave = tid >> 6;
-    if (lane < 8) {
-#pragma unroll
-      for (int e = 0; e < VEC; ++e) red[wave * CC + lane * VEC + e] = psum[e];
-    }
     __syncthreads();
-    if (tid < CC) {
-      float t = 0.f;
-#pragma unroll
-      for (int wv = 0; wv < NT / 64; ++wv) t += red[wv * CC + tid];
-      const int ntiles = tiles_x * (a.H / TYL);
-      a.pool[((size_t)b * ntiles + blockIdx.x) * a.C + blockIdx.y * CC + tid] = t;
-    }
+    const int ntiles = tiles_x * (a.H / kPoolSegRows);
+    pool_segments_store<CC, NT>(red, TYL / kPoolSegRows, tid, a.pool + (size_t)b * ntiles * a.C + blockIdx.y * CC, a.C,
+                                ty * (TYL / kPoolSegRows), tiles_x, tx);
   }
 }
 
 static int g_dw_dbg = 0;
 void dwconv_debug(int v) { g_dw_dbg = v; }  // bits 0-1: timing ablations
 static int dw_tx(int W) { return (W % 32 == 0) ? 32 : ((W % 16 == 0) ? 16 : 8); }
-static int dw_tyl(int H) { return (H % 64 == 0) ? 64 : ((H % 32 == 0) ? 32 : ((H % 16 == 0) ? 16 : 8)); }
-int dwconv_ntiles(int H, int W) { return (H / dw_tyl(H)) * (W / dw_tx(W)); }
+// Strip height: as tall as possible (fewer halo rows) while the launch still has >= 1024 workgroups to
+// fill 256 CUs; small batches get shorter strips.  `chunks` = C / channels per WG.  The pool slab does
+// not depend on the choice (8-row segments), so results are bitwise independent of the batch size.
+int dw_pick_tyl(int B, int H, int W, int chunks) {
+  const int tiles_x = W / dw_tx(W);
+  const int cand[4] = {64, 32, 16, 8};
+  for (int i = 0; i < 4; ++i)
+    if (H % cand[i] == 0 && (long)tiles_x * (H / cand[i]) * chunks * B >= 1024) return cand[i];
+  return 8;
+}
+int dwconv_ntiles(int H, int W) { return (H / kPoolSegRows) * (W / dw_tx(W)); }
 
 template <typename T>
 static hipError_t launch_dw_t(const DwArgs& a, hipStream_t s) {
   constexpr int CC = 8 * Elem<T>::VEC;
   if (a.C % CC || a.H % 8 || a.W % 8) return hipErrorInvalidValue;
-  const int tx = dw_tx(a.W), tyl = dw_tyl(a.H);
+  const int tx = dw_tx(a.W), tyl = dw_pick_tyl(a.B, a.H, a.W, a.C / CC);
   dim3 grid((a.W / tx) * (a.H / tyl), a.C / CC, a.B);
   static const std::string names[3] = {std::string("dwconv3x3_kernel<") + TypeName<T>::value + ", 32, 4>",
                                        std::string("dwconv3x3_kernel<") + TypeName<T>::value + ", 16, 4>",

@@ -41,7 +41,7 @@ __global__ void __launch_bounds__(256) dwx_kernel(const DwxArgs a, const int TYL
   __shared__ float aff1s[2][K];
   __shared__ __align__(16) float aff2s[2][CC];
   __shared__ __align__(16) T wds[9 * CC];  // depthwise weights of this channel chunk, packed in T
-  __shared__ float red[(NT / 64) * CC];
+  __shared__ float red[8 * (NT / 64) * CC];  // [8-row segment][wave][channel]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int cl = tid & 7, xl = tid >> 3;
@@ -207,6 +207,7 @@ __global__ void __launch_bounds__(256) dwx_kernel(const DwxArgs a, const int TYL
         st_vec<T>(out + ((size_t)(y0 + r - 2) * a.W + x0 + xl) * a.Chid, ov);
 #pragma unroll
         for (int e = 0; e < VEC; ++e) psum[e] += (float)ov[e];
+        if (a.pool && ((r - 2) & 7) == 7) pool_segment_flush<VEC>(psum, red + (((r - 2) >> 3) * (NT / 64) + wave) * CC, lane);
       }
 #pragma unroll
       for (int e = 0; e < VEC; ++e) {
@@ -217,22 +218,10 @@ __global__ void __launch_bounds__(256) dwx_kernel(const DwxArgs a, const int TYL
     }
   }
   if (a.pool) {
-#pragma unroll
-    for (int o = 8; o < 64; o <<= 1)
-#pragma unroll
-      for (int e = 0; e < VEC; ++e) psum[e] += __shfl_xor(psum[e], o, 64);
-    if (lane < 8) {
-#pragma unroll
-      for (int e = 0; e < VEC; ++e) red[wave * CC + lane * VEC + e] = psum[e];
-    }
     __syncthreads();
-    if (tid < CC) {
-      float t = 0.f;
-#pragma unroll
-      for (int wv = 0; wv < NT / 64; ++wv) t += red[wv * CC + tid];
-      const int ntiles = tiles_x * (a.H / TYL);
-      a.pool[((size_t)b * ntiles + blockIdx.x) * a.Chid + cbase + tid] = t;
-    }
+    const int ntiles = tiles_x * (a.H / kPoolSegRows);
+    pool_segments_store<CC, NT>(red, TYL / kPoolSegRows, tid, a.pool + (size_t)b * ntiles * a.Chid + cbase, a.Chid,
+                                ty * (TYL / kPoolSegRows), tiles_x, tx);
   }
 }
 
@@ -242,7 +231,7 @@ bool dwx_supported(int dtype, int Cin, int Chid, int H, int W) {
 
 template <typename T, int KS>
 static hipError_t launch_dwx_k(const DwxArgs& a, hipStream_t s) {
-  const int tyl = (a.H % 64 == 0) ? 64 : ((a.H % 32 == 0) ? 32 : ((a.H % 16 == 0) ? 16 : 8));
+  const int tyl = dw_pick_tyl(a.B, a.H, a.W, a.Chid / 64);  // same strips as dwconv3x3 (pool slab layout)
   dim3 grid((a.W / 32) * (a.H / tyl), a.Chid / 64, a.B);
   static const std::string name = std::string("dwx_kernel<") + TypeName<T>::value + ", " + std::to_string(KS) + ">";
   note_kernel(name.c_str());

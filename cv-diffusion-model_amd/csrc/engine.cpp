@@ -562,11 +562,12 @@ struct Run {
       chk(launch_pw_gemm(dt, g, s));
     }
     ar->free(as); ar->free(ab);
-    const size_t kv = ar->alloc((size_t)B * w.heads * 32 * 33 * 4);
+    const int nsplit = linattn_nsplit(N);
+    const size_t kv = ar->alloc((size_t)nsplit * B * w.heads * 32 * 33 * 4);
     const size_t ao = ar->alloc((size_t)M * w.inner * es());
     if (!dry) {
       AttnArgs a{};
-      a.qkv = p(qkv); a.B = B; a.N = N; a.heads = w.heads; a.kv = p<float>(kv); a.out = p(ao);
+      a.qkv = p(qkv); a.B = B; a.N = N; a.heads = w.heads; a.kv = p<float>(kv); a.out = p(ao); a.nsplit = nsplit;
       chk(launch_linattn_kv(dt, a, s));
       chk(launch_linattn_out(dt, a, s));
     }

@@ -101,7 +101,8 @@ struct DwxArgs {
 };
 bool dwx_supported(int dtype, int Cin, int Chid, int H, int W);
 hipError_t launch_dwx(int dtype, const DwxArgs& a, hipStream_t s);
-int dwconv_ntiles(int H, int W);
+int dwconv_ntiles(int H, int W);  // pool slab entries per image: (H/8 row segments) x (W / strip width)
+int dw_pick_tyl(int B, int H, int W, int chunks);
 void dwconv_debug(int v);  // timing ablations (bit 0: no MACs, bit 1: no activation); results are wrong when set
 
 // Squeeze-and-Excitation MLP (efficient_unet.py:96-100) in two launches.
@@ -182,9 +183,12 @@ int conv3x3_ntiles(int Ho, int Wo);
 // Linear attention core (efficient_unet.py:288-302) on qkv NHWC [B][N][3*inner].
 struct AttnArgs {
   const void* qkv; int B, N, heads;  // dim_head = 32
-  float* kv;      // [B][heads][32][33]: rows 0..31 = kv[d][e], column 32 = ksum[d]
+  float* kv;      // [nsplit][B][heads][32][33]: rows 0..31 = kv[d][e], column 32 = ksum[d]; partial sums over
+                  // position ranges, added in split order by the second pass (deterministic)
   void* out;      // [B][N][inner] T
+  int nsplit;     // linattn_nsplit(N)
 };
+int linattn_nsplit(int N);
 hipError_t launch_linattn_kv(int dtype, const AttnArgs& a, hipStream_t s);
 hipError_t launch_linattn_out(int dtype, const AttnArgs& a, hipStream_t s);
 

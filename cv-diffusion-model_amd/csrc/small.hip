@@ -296,17 +296,19 @@ hipError_t launch_silu_rows(const float* in, float* out, int64_t n, hipStream_t 
 // (heads d) (:284-286).  phi(x) = elu(x)+1 on q and k only.
 __device__ __forceinline__ float phi(float x) { return x > 0.f ? x + 1.f : __expf(x); }
 
-// pass 1: kv[d][e] = sum_n phi(k[n][d]) v[n][e], ksum[d] = sum_n phi(k[n][d]); one block per (head, image).
+// pass 1: kv[d][e] = sum_n phi(k[n][d]) v[n][e], ksum[d] = sum_n phi(k[n][d]); one block per
+// (head, image, position split): the splits keep small batches from running on a handful of CUs.
 template <typename T>
 __global__ void __launch_bounds__(256) linattn_kv_kernel(const AttnArgs a) {
   constexpr int CH = 64;  // positions per staged chunk
   __shared__ float sk[CH][33], sv[CH][33];
-  const int h = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const int h = blockIdx.x, b = blockIdx.y, sp = blockIdx.z, tid = threadIdx.x;
   const int inner = a.heads * 32, ld = 3 * inner;
   const T* base = reinterpret_cast<const T*>(a.qkv) + (size_t)b * a.N * ld;
   const int d = tid >> 3, e0 = (tid & 7) * 4;
   float acc[4] = {0.f, 0.f, 0.f, 0.f}, ks = 0.f;
-  for (int n0 = 0; n0 < a.N; n0 += CH) {
+  const int span = a.N / a.nsplit;
+  for (int n0 = sp * span; n0 < (sp + 1) * span; n0 += CH) {
     for (int i = tid; i < CH * 32; i += 256) {
       const int n = i >> 5, c = i & 31;
       const T* row = base + (size_t)(n0 + n) * ld;
@@ -323,7 +325,7 @@ __global__ void __launch_bounds__(256) linattn_kv_kernel(const AttnArgs a) {
     }
     __syncthreads();
   }
-  float* out = a.kv + (size_t)(b * a.heads + h) * 32 * 33;
+  float* out = a.kv + ((size_t)(sp * a.B + b) * a.heads + h) * 32 * 33;
 #pragma unroll
   for (int q = 0; q < 4; ++q) out[d * 33 + e0 + q] = acc[q];
   if ((tid & 7) == 0) out[d * 33 + 32] = ks;
@@ -338,7 +340,12 @@ __global__ void __launch_bounds__(256) linattn_out_kernel(const AttnArgs a) {
   const int n0 = blockIdx.x * 64;
   const int inner = a.heads * 32, ld = 3 * inner;
   const float* kvp = a.kv + (size_t)(b * a.heads + h) * 32 * 33;
-  for (int i = tid; i < 32 * 33; i += 256) skv[i] = kvp[i];
+  const size_t sps = (size_t)a.B * a.heads * 32 * 33;
+  for (int i = tid; i < 32 * 33; i += 256) {
+    float v = kvp[i];
+    for (int sp = 1; sp < a.nsplit; ++sp) v += kvp[sp * sps + i];
+    skv[i] = v;
+  }
   const T* base = reinterpret_cast<const T*>(a.qkv) + (size_t)b * a.N * ld;
   for (int i = tid; i < 64 * 32; i += 256) {
     const int n = i >> 5, c = i & 31;
@@ -363,9 +370,16 @@ __global__ void __launch_bounds__(256) linattn_out_kernel(const AttnArgs a) {
   for (int q = 0; q < 8; ++q) o[q] = (T)(acc[q] * inv);
 }
 
+// Position splits of pass 1: 128 positions per partial, at most 8 -- a function of N only, so the
+// summation order (and the result bits) do not depend on the batch size.
+int linattn_nsplit(int N) {
+  int ns = 1;
+  while (ns < 8 && N % (ns * 2 * 128) == 0) ns *= 2;
+  return ns;
+}
 hipError_t launch_linattn_kv(int dtype, const AttnArgs& a, hipStream_t s) {
-  if (a.N % 64) return hipErrorInvalidValue;
-  dim3 grid(a.heads, a.B);
+  if (a.nsplit < 1 || a.N % (64 * a.nsplit)) return hipErrorInvalidValue;
+  dim3 grid(a.heads, a.B, a.nsplit);
   switch (dtype) {
     case 0: hipLaunchKernelGGL(linattn_kv_kernel<float>, grid, dim3(256), 0, s, a); break;
     case 1: hipLaunchKernelGGL(linattn_kv_kernel<half_t>, grid, dim3(256), 0, s, a); break;
