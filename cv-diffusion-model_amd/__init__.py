@@ -10,7 +10,7 @@ repository root) or `importlib.import_module("cv-diffusion-model_amd")`.
 """
 from .unet import (EfficientUNet, EfficientUNetConfig, create_efficient_unet, InvertedResidualBlock,
                    LinearAttention, Downsample, Upsample)
-from .scheduler import LCMScheduler, LCMSchedulerOutput, get_lcm_timesteps
+from .scheduler import LCMScheduler, LCMSchedulerOutput, LCMDenoisingLoop, get_lcm_timesteps
 from .pipeline import LowLightDiffusion, LowLightDiffusionOutput, normalize_image, denormalize_image
 from .sharding import shard_range, enhance_sharded, all_gather_batch
 from .build import build_library, library_path
@@ -19,7 +19,7 @@ from .hostio import (load_checkpoint, extract_state_dict, preprocess_array, post
 
 __all__ = [
     "EfficientUNet", "EfficientUNetConfig", "create_efficient_unet", "InvertedResidualBlock", "LinearAttention",
-    "Downsample", "Upsample", "LCMScheduler", "LCMSchedulerOutput", "get_lcm_timesteps", "LowLightDiffusion",
+    "Downsample", "Upsample", "LCMScheduler", "LCMSchedulerOutput", "LCMDenoisingLoop", "get_lcm_timesteps", "LowLightDiffusion",
     "LowLightDiffusionOutput", "normalize_image", "denormalize_image", "shard_range", "enhance_sharded",
     "all_gather_batch", "build_library", "library_path", "load_checkpoint", "extract_state_dict",
     "preprocess_array", "postprocess_array", "resize_bilinear", "preprocess_device", "postprocess_device",

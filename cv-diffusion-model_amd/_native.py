@@ -49,7 +49,7 @@ class Config(C.Structure):
 class StepCoef(C.Structure):
     _fields_ = [
         ("sqrt_alpha_t", C.c_float), ("sqrt_beta_t", C.c_float), ("sqrt_alpha_prev", C.c_float),
-        ("sqrt_beta_prev", C.c_float), ("is_last", C.c_int), ("v_prediction", C.c_int),
+        ("sqrt_beta_prev", C.c_float), ("is_last", C.c_int), ("v_prediction", C.c_int), ("clamp_x0", C.c_int),
     ]
 
 

@@ -352,6 +352,7 @@ __global__ void __launch_bounds__(256) final_conv_mfma_kernel(const FinalConvArg
         float x0v;
         if (a.coef.vpred) x0v = a.coef.sa * xv - a.coef.sb * e;
         else x0v = (xv - a.coef.sb * e) / a.coef.sa;
+        if (a.coef.clamp_x0) x0v = fminf(fmaxf(x0v, -1.f), 1.f);
         float pv = x0v;
         if (!a.coef.is_last) pv = a.coef.sap * x0v + a.coef.sbp * a.noise[idx];
         a.prev[idx] = pv;

@@ -950,7 +950,7 @@ int llie_lcm_step(const float* mo, const float* sample, const float* noise, floa
                   int64_t n, const llie_step_coef* k, llie_stream stream) {
   if (!mo || !sample || !prev || !k || n <= 0) return LLIE_ERR_ARG;
   if (!k->is_last && !noise) return LLIE_ERR_ARG;
-  StepCoef c{k->sqrt_alpha_t, k->sqrt_beta_t, k->sqrt_alpha_prev, k->sqrt_beta_prev, k->is_last, k->v_prediction};
+  StepCoef c{k->sqrt_alpha_t, k->sqrt_beta_t, k->sqrt_alpha_prev, k->sqrt_beta_prev, k->is_last, k->v_prediction, k->clamp_x0};
   hipError_t e = launch_lcm_step(mo, sample, noise, prev, x0, clamped, n, c, reinterpret_cast<hipStream_t>(stream));
   if (e != hipSuccess) { set_err("lcm_step: %s", hipGetErrorString(e)); return (int)e; }
   return LLIE_OK;
@@ -987,7 +987,7 @@ static int enhance_sequence(llie_ctx* c, const float* low, const float* noise, c
     int rc;
     if (fuse) {
       Run::FusedStep fs{StepCoef{coefs[i].sqrt_alpha_t, coefs[i].sqrt_beta_t, coefs[i].sqrt_alpha_prev, coefs[i].sqrt_beta_prev,
-                                 coefs[i].is_last, coefs[i].v_prediction},
+                                 coefs[i].is_last, coefs[i].v_prediction, coefs[i].clamp_x0},
                         nz, prev, last ? enhanced : nullptr};
       rc = unet_forward_impl(c, cur, low, t_dev + (size_t)i * batch, 1, preds ? preds + (size_t)i * n : nullptr, &fs, batch,
                              uws, uws_bytes, stream);

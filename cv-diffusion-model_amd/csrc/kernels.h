@@ -155,7 +155,7 @@ hipError_t launch_init_conv(int dtype, const InitConvArgs& a, hipStream_t s);
 int init_conv_ntiles(int H, int W);
 //   final: NHWC T -> affine + SiLU -> 3x3 conv C->Cout(3) -> fp32 NCHW; the MFMA variant (2-byte T)
 //   can apply LCMScheduler.step to its own output in the epilogue (fuse_step).
-struct StepCoef { float sa, sb, sap, sbp; int is_last; int vpred; };
+struct StepCoef { float sa, sb, sap, sbp; int is_last; int vpred; int clamp_x0; };
 struct FinalConvArgs {
   const void* in; const float* as; const float* ab;
   const float* w; const float* bias;             // [9][C][4] (repacked, zero padded), [Cout]

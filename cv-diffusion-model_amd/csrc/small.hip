@@ -764,6 +764,7 @@ __global__ void lcm_step_kernel(const float* eps, const float* x, const float* n
   float x0;
   if (c.vpred) x0 = c.sa * xv - c.sb * e;
   else x0 = (xv - c.sb * e) / c.sa;
+  if (c.clamp_x0) x0 = fminf(fmaxf(x0, -1.f), 1.f);
   float p = x0;
   if (!c.is_last) p = c.sap * x0 + c.sbp * noise[i];
   prev[i] = p;

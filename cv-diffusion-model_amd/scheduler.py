@@ -163,3 +163,84 @@ def get_lcm_timesteps(num_inference_steps: int = 4, num_train_timesteps: int = 1
     origin = [(i + 1) * c - 1 for i in range(original_inference_steps)]
     skip = len(origin) // num_inference_steps
     return list(reversed(origin[::skip][:num_inference_steps]))
+
+
+class LCMDenoisingLoop:
+    """The deployment loop's scheduler semantics (src/export/android_pipeline.py:191-277) as a selectable
+    mode: scaled-linear alpha-bar table in float64 WITHOUT the zero-SNR rescale, and x0 clamped to [-1, 1]
+    before re-noising.  Interface as the reference class (`timesteps`, `alphas_cumprod`, `add_noise`,
+    `step`), with device tensors instead of numpy arrays; it also answers the calls
+    `LowLightDiffusion.enhance` makes on its scheduler, so `LowLightDiffusion(scheduler=LCMDenoisingLoop())`
+    runs the whole loop with these semantics.
+
+    The per-step scalars are formed in float64 like the reference and rounded once to fp32 for the
+    kernel; the reference's own result dtype depends on numpy's promotion rules (float64 under
+    NumPy >= 2), so parity is to fp32 rounding, not bitwise."""
+
+    def __init__(self, num_train_timesteps: int = 1000, num_inference_steps: int = 4,
+                 beta_start: float = 0.00085, beta_end: float = 0.012):
+        import numpy as np
+        self.num_train_timesteps = num_train_timesteps
+        self.num_inference_steps = num_inference_steps
+        betas = np.linspace(beta_start ** 0.5, beta_end ** 0.5, num_train_timesteps) ** 2
+        self.alphas = 1.0 - betas
+        self.alphas_cumprod = np.cumprod(self.alphas)
+        self.config = SimpleNamespace(num_train_timesteps=num_train_timesteps, prediction_type="epsilon",
+                                      original_inference_steps=50)
+        self._acp_dev = {}
+        self._step_index = None
+        self.set_timesteps(num_inference_steps)
+
+    def _get_lcm_timesteps(self):
+        import numpy as np
+        c = self.num_train_timesteps // 50
+        lcm = np.arange(1, 51) * c - 1
+        skip = len(lcm) // self.num_inference_steps
+        return lcm[::skip][:self.num_inference_steps][::-1].copy()
+
+    def set_timesteps(self, num_inference_steps: int = 4, device=None) -> None:
+        self.num_inference_steps = num_inference_steps
+        self.timesteps = self._get_lcm_timesteps()
+        self._timestep_list = [int(v) for v in self.timesteps]
+        self._step_index = 0
+
+    def step_coefficients(self, timestep: int) -> N.StepCoef:
+        t = int(timestep)
+        idx = self._timestep_list.index(t)
+        prev_t = self._timestep_list[idx + 1] if idx + 1 < len(self._timestep_list) else 0
+        a_t = float(self.alphas_cumprod[t])
+        a_p = float(self.alphas_cumprod[prev_t] if prev_t > 0 else self.alphas_cumprod[0])
+        return N.StepCoef(math.sqrt(a_t), math.sqrt(1 - a_t), math.sqrt(a_p), math.sqrt(1 - a_p), int(prev_t == 0), 0, 1)
+
+    def step(self, noise_pred: torch.Tensor, timestep: int, sample: torch.Tensor,
+             noise: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """android_pipeline.py:240-265 -> the next sample (x0 after the last timestep).  `noise=` supplies
+        the re-noising draw (the reference draws it with np.random.randn, :262)."""
+        _require_cuda(sample, "LCMDenoisingLoop.step")
+        coef = self.step_coefficients(int(timestep))
+        sample_c = sample.detach().float().contiguous()
+        mo = noise_pred.detach().float().contiguous()
+        if not coef.is_last and noise is None:
+            noise = torch.randn_like(sample_c)
+        prev = torch.empty_like(sample_c)
+        with torch.cuda.device(sample.device):
+            N.check(N.lib().llie_lcm_step(mo.data_ptr(), sample_c.data_ptr(),
+                                          None if coef.is_last else noise.float().contiguous().data_ptr(),
+                                          prev.data_ptr(), None, None, sample_c.numel(), coef,
+                                          torch.cuda.current_stream(sample.device).cuda_stream), "LCMDenoisingLoop.step")
+        return prev
+
+    def add_noise(self, original: torch.Tensor, noise: torch.Tensor, timestep: int) -> torch.Tensor:
+        """android_pipeline.py:228-238 (one scalar timestep for the whole batch)."""
+        _require_cuda(original, "LCMDenoisingLoop.add_noise")
+        a, b = original.detach().float().contiguous(), noise.detach().float().contiguous()
+        key = (a.device.type, a.device.index)
+        if key not in self._acp_dev:
+            self._acp_dev[key] = torch.from_numpy(self.alphas_cumprod).to(device=a.device, dtype=torch.float32).contiguous()
+        t = torch.full((a.shape[0],), int(timestep), dtype=torch.long, device=a.device)
+        out = torch.empty_like(a)
+        with torch.cuda.device(a.device):
+            N.check(N.lib().llie_add_noise(a.data_ptr(), b.data_ptr(), t.data_ptr(), self._acp_dev[key].data_ptr(),
+                                           out.data_ptr(), a.shape[0], a[0].numel(), 0,
+                                           torch.cuda.current_stream(a.device).cuda_stream), "LCMDenoisingLoop.add_noise")
+        return out

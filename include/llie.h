@@ -78,6 +78,9 @@ typedef struct llie_step_coef {
   float sqrt_alpha_prev, sqrt_beta_prev; /* for prev_t; ignored when is_last */
   int   is_last;                         /* prev_t == 0 -> prev_sample = x0 (lcm_scheduler.py:228-229) */
   int   v_prediction;                    /* 0 epsilon (:217), 1 v_prediction (:220) */
+  int   clamp_x0;                        /* 1: x0 = clip(x0, -1, 1) before re-noising -- the deployment loop's
+                                            semantics (src/export/android_pipeline.py:250-252); the LCMScheduler
+                                            has that clamp commented out (lcm_scheduler.py:224-225) -> 0 */
 } llie_step_coef;
 
 const char* llie_last_error(void);

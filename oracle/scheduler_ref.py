@@ -85,3 +85,39 @@ def get_velocity(tab: LCMTables, sample: torch.Tensor, noise: torch.Tensor, t: t
     """lcm_scheduler.py:282-305."""
     a = tab.alphas_cumprod.to(sample.dtype)[t]
     return _bcast(a ** 0.5, sample) * noise - _bcast((1 - a) ** 0.5, sample) * sample
+
+
+# ---------------------------------------------------------------------------------------------
+# Deployment loop (src/export/android_pipeline.py:191-277): numpy float64 tables, no zero-SNR rescale,
+# x0 clamped to [-1, 1] before re-noising.  Restated in float64 numpy like the reference computes it
+# (np.float64 scalars promote the float32 arrays under NumPy >= 2).
+def deploy_alphas_cumprod(num_train_timesteps: int = 1000, beta_start: float = 0.00085, beta_end: float = 0.012):
+    import numpy as np
+    betas = np.linspace(beta_start ** 0.5, beta_end ** 0.5, num_train_timesteps) ** 2  # :209
+    return np.cumprod(1.0 - betas)                                                      # :210-211
+
+
+def deploy_timesteps(num_inference_steps: int, num_train_timesteps: int = 1000):
+    import numpy as np
+    c = num_train_timesteps // 50                          # :218-219
+    lcm = np.arange(1, 51) * c - 1                         # :221
+    skip = len(lcm) // num_inference_steps                 # :223
+    return lcm[::skip][:num_inference_steps][::-1].copy()  # :224-226
+
+
+def deploy_step(acp, timesteps, noise_pred, t: int, sample, noise):
+    """LCMDenoisingLoop.step (:240-265); `noise` replaces the np.random.randn draw of :262."""
+    import numpy as np
+    idx = int(np.where(timesteps == t)[0][0])
+    prev_t = int(timesteps[idx + 1]) if idx + 1 < len(timesteps) else 0
+    a_t = acp[t]
+    a_p = acp[prev_t] if prev_t > 0 else acp[0]
+    x0 = np.clip((sample - np.sqrt(1 - a_t) * noise_pred) / np.sqrt(a_t), -1, 1)
+    if prev_t == 0:
+        return x0
+    return np.sqrt(a_p) * x0 + np.sqrt(1 - a_p) * noise
+
+
+def deploy_add_noise(acp, original, noise, t: int):
+    import numpy as np
+    return np.sqrt(acp[t]) * original + np.sqrt(1 - acp[t]) * noise  # :228-238

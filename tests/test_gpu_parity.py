@@ -209,6 +209,49 @@ def test_enhance_small256_fp32_vs_reference_samples(golden, dev):
     check("enhanced", out.enhanced)
 
 
+def test_deploy_loop_step_and_add_noise(golden, dev):
+    """LCMDenoisingLoop semantics (android_pipeline.py:228-265: no zero-SNR rescale, x0 clamp) against vectors
+    the reference class produced in float64; the kernel works in fp32 -> tolerance a few fp32 ulps of |x|<=4."""
+    g = golden("deploy_loop_kat.npz")
+    loop = M.LCMDenoisingLoop(num_inference_steps=4)
+    sample, eps = torch.from_numpy(g["sample"]).to(dev), torch.from_numpy(g["noise_pred"]).to(dev)
+    for t in loop.timesteps.tolist():
+        out = loop.step(eps, t, sample, noise=torch.from_numpy(g[f"noise_{t}"]).to(dev))
+        assert max_abs(out.cpu(), g[f"step_{t}"]) < 2e-6
+    x0, nz = torch.from_numpy(g["x0"]).to(dev), torch.from_numpy(g["add_noise_noise"]).to(dev)
+    for t in (19, 499, 999):
+        assert max_abs(loop.add_noise(x0, nz, t).cpu(), g[f"add_noise_{t}"]) < 1e-6
+
+
+@pytest.mark.parametrize("cd", [None, "fp16"])
+def test_enhance_with_deploy_loop_semantics(dev, cd):
+    """`LowLightDiffusion(scheduler=LCMDenoisingLoop())`: the whole loop (fused-step output head for fp16)
+    against the oracle's UNet + the float64 restatement of the deployment step."""
+    from oracle import scheduler_ref as S
+    m, sd, spec = small_model(64, dev)
+    dm = M.LowLightDiffusion(unet=m.unet, scheduler=M.LCMDenoisingLoop(num_inference_steps=4), image_size=64)
+    dm.compute_dtype = cd
+    try:
+        low = torch.rand(2, 3, 64, 64, generator=torch.Generator().manual_seed(11)) * 2 - 1
+        noise = oracle.draw_noise(2, 64, 4, seed=77)
+        out = dm.enhance(low.to(dev), 4, noise=torch.stack(noise), return_intermediate=True)
+        acp, ts = S.deploy_alphas_cumprod(), S.deploy_timesteps(4)
+        lat = noise[0]
+        for i, t in enumerate(ts.tolist()):
+            eps = oracle.unet_forward(sd, spec, torch.cat([lat, low], 1), torch.full((2,), t, dtype=torch.long))
+            nz = noise[i + 1].numpy() if i + 1 < 4 else None
+            lat = torch.from_numpy(S.deploy_step(acp, ts, eps.numpy(), t, lat.numpy(), nz)).float()
+            if cd is None:
+                assert max_abs(out.intermediate[i].cpu(), lat) < 1e-3
+        if cd is None:
+            assert max_abs(out.enhanced.cpu(), lat.clamp(-1, 1)) < 1e-3
+        else:
+            assert psnr01(out.enhanced.cpu(), lat) > 40.0
+        assert out.intermediate[-1].abs().max() <= 1.0      # the final sample is the clamped x0
+    finally:
+        dm.compute_dtype = None
+
+
 def test_enhance_vs_oracle_fresh_inputs(dev):
     """Oracle run on the GPU box itself (not a stored vector): 6- and 8-step schedules, B=3 (ragged)."""
     m, sd, spec = small_model(64, dev)

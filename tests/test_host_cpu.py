@@ -208,3 +208,21 @@ def test_enhance_sharded_world2_gloo(tmp_path):
     outs = [p.communicate(timeout=240)[0] for p in procs]
     for p, o in zip(procs, outs):
         assert p.returncode == 0 and "ok" in o, o[-2000:]
+
+
+def test_deploy_loop_host_tables(golden):
+    """LCMDenoisingLoop host side (android_pipeline.py:197-226): float64 table without the zero-SNR
+    rescale, reversed timestep list, clamp flag and final-step rule in the per-step coefficients."""
+    g = golden("deploy_loop_kat.npz")
+    loop = M.LCMDenoisingLoop(num_inference_steps=4)
+    assert np.array_equal(loop.alphas_cumprod, g["alphas_cumprod"])
+    for n in (4, 6, 8):
+        assert np.array_equal(M.LCMDenoisingLoop(num_inference_steps=n).timesteps, g[f"timesteps_{n}"])
+    c = loop.step_coefficients(739)
+    assert c.clamp_x0 == 1 and c.is_last == 0 and c.v_prediction == 0
+    assert abs(c.sqrt_alpha_prev - float(np.sqrt(g["alphas_cumprod"][499]))) < 1e-7
+    assert loop.step_coefficients(19).is_last == 1
+    s = M.LCMScheduler(rescale_betas_zero_snr=True); s.set_timesteps(4)
+    assert s.step_coefficients(739).clamp_x0 == 0          # the scheduler keeps x0 unclamped (lcm_scheduler.py:224-225)
+    with pytest.raises(RuntimeError):
+        loop.step(torch.zeros(1, 3, 8, 8), 739, torch.zeros(1, 3, 8, 8))   # CPU tensors: no fallback

@@ -206,3 +206,19 @@ def test_enhance_small256_samples(golden):
         check(f"noise_pred_{i}", out["noise_pred"][i])
         check(f"latents_{i}", out["intermediate"][i])
     check("enhanced", out["enhanced"])
+
+
+# ------------------------------------------------------------------ deployment loop (android_pipeline.py:191-277)
+def test_deploy_loop_restatement_vs_reference(golden):
+    from oracle import scheduler_ref as S
+    g = golden("deploy_loop_kat.npz")
+    acp = S.deploy_alphas_cumprod()
+    assert np.array_equal(acp, g["alphas_cumprod"])          # float64, bit-identical
+    for n in (4, 6, 8):
+        assert np.array_equal(S.deploy_timesteps(n), g[f"timesteps_{n}"])
+    ts = S.deploy_timesteps(4)
+    for t in ts.tolist():
+        out = S.deploy_step(acp, ts, g["noise_pred"], t, g["sample"], g[f"noise_{t}"])
+        assert out.dtype == g[f"step_{t}"].dtype and np.array_equal(out, g[f"step_{t}"])
+    for t in (19, 499, 999):
+        assert np.array_equal(S.deploy_add_noise(acp, g["x0"], g["add_noise_noise"], t), g[f"add_noise_{t}"])
