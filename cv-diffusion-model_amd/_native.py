@@ -24,6 +24,8 @@ EXPORTS = [
     "llie_lcm_step", "llie_add_noise", "llie_enhance", "llie_algorithmic_bytes", "llie_flops",
     "llie_profile_begin", "llie_profile_end", "llie_enhance_workspace_bytes",
     "llie_preprocess_u8", "llie_postprocess_u8", "llie_profile_report", "llie_pw_gemm", "llie_pw_gemm_tile_rows", "llie_dwconv3x3", "llie_dwconv3x3_tiles", "llie_tune",
+    "llie_grad_numel", "llie_param_grad_offset", "llie_train_workspace_bytes", "llie_unet_train_forward",
+    "llie_unet_backward", "llie_module_backward",
 ]
 K_GEMM, K_DW, K_CONV3, K_SE = 1, 2, 4, 8
 
@@ -98,6 +100,15 @@ def lib() -> C.CDLL:
     L.llie_dwconv3x3.argtypes = [ci, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, vp]
     L.llie_dwconv3x3_tiles.argtypes = [ci, ci]
     L.llie_tune.argtypes = [C.c_char_p, ci]
+    L.llie_grad_numel.argtypes = [vp]
+    L.llie_grad_numel.restype = i64
+    L.llie_param_grad_offset.argtypes = [vp, ci]
+    L.llie_param_grad_offset.restype = i64
+    L.llie_train_workspace_bytes.argtypes = [vp, ci, ci, ci]
+    L.llie_train_workspace_bytes.restype = i64
+    L.llie_unet_train_forward.argtypes = [vp, vp, vp, vp, vp, ci, vp, i64, vp]
+    L.llie_unet_backward.argtypes = [vp, vp, vp, ci, vp, i64, vp]
+    L.llie_module_backward.argtypes = [vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, vp, i64, vp]
     L.llie_profile_report.argtypes = [vp, C.c_char_p, C.c_size_t]
     L.llie_profile_begin.argtypes = [vp, ci]
     L.llie_profile_end.argtypes = [vp, ci, C.POINTER(C.c_double), C.POINTER(i64), C.POINTER(i64)]
@@ -175,6 +186,18 @@ class Handle:
         if n < 0:
             check(int(n), "llie_workspace_bytes")
         return int(n)
+
+    def train_workspace_bytes(self, batch: int, h: int = 0, w: int = 0) -> int:
+        n = self._L.llie_train_workspace_bytes(self.h, batch, h, w)
+        if n < 0:
+            check(int(n), "llie_train_workspace_bytes")
+        return int(n)
+
+    def grad_numel(self) -> int:
+        return int(self._L.llie_grad_numel(self.h))
+
+    def grad_offsets(self) -> List[int]:
+        return [int(self._L.llie_param_grad_offset(self.h, i)) for i in range(self._L.llie_num_params(self.h))]
 
     def enhance_workspace_bytes(self, batch: int, max_steps: int) -> int:
         n = self._L.llie_enhance_workspace_bytes(self.h, batch, max_steps)

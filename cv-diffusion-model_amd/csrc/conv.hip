@@ -405,7 +405,7 @@ __global__ void __launch_bounds__(WM* WN * 64) conv3x3_kernel(const Conv3Args a)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
-  const int Ho = MODE == 0 ? a.Hi / 2 : a.Hi * 2, Wo = MODE == 0 ? a.Wi / 2 : a.Wi * 2;
+  const int Ho = MODE == 0 ? a.Hi / 2 : (MODE == 1 ? a.Hi * 2 : a.Hi), Wo = MODE == 0 ? a.Wi / 2 : (MODE == 1 ? a.Wi * 2 : a.Wi);
   const int nb = a.Cout / BN, tiles_x = Wo / TW, tiles = tiles_x * (Ho / TH);
   int bid = blockIdx.x;
   const int ntile = bid % nb; bid /= nb;
@@ -461,6 +461,14 @@ __global__ void __launch_bounds__(WM* WN * 64) conv3x3_kernel(const Conv3Args a)
       vec_t v;
       if (MODE == 0) {
         const int gy = 2 * oy0 - 1 + ppy, gx = 2 * ox0 - 1 + ppx;
+        if (gy >= 0 && gy < a.Hi && gx >= 0 && gx < a.Wi) {
+          v = ld_vec<T>(in + ((size_t)gy * a.Wi + gx) * a.Cin + c0 + kv);
+        } else {
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) v[e] = (T)0.f;
+        }
+      } else if (MODE == 2) {
+        const int gy = oy0 - 1 + ppy, gx = ox0 - 1 + ppx;
         if (gy >= 0 && gy < a.Hi && gx >= 0 && gx < a.Wi) {
           v = ld_vec<T>(in + ((size_t)gy * a.Wi + gx) * a.Cin + c0 + kv);
         } else {
@@ -606,7 +614,7 @@ static hipError_t launch_conv_cfg(const Conv3Args& a, hipStream_t s) {
     if (e != hipSuccess) return e;
     attr_done = true;
   }
-  const int Ho = MODE == 0 ? a.Hi / 2 : a.Hi * 2, Wo = MODE == 0 ? a.Wi / 2 : a.Wi * 2;
+  const int Ho = MODE == 0 ? a.Hi / 2 : (MODE == 1 ? a.Hi * 2 : a.Hi), Wo = MODE == 0 ? a.Wi / 2 : (MODE == 1 ? a.Wi * 2 : a.Wi);
   const unsigned grid = (unsigned)(a.B * (Ho / 8) * (Wo / TW) * (a.Cout / BN));
   static const std::string name = std::string("conv3x3_kernel<") + TypeName<T>::value + ", " + std::to_string(MODE) + ", " +
                                   std::to_string(TW) + ", " + std::to_string(BN) + ", " + std::to_string(WM) + ", " +
@@ -618,7 +626,7 @@ static hipError_t launch_conv_cfg(const Conv3Args& a, hipStream_t s) {
 
 template <typename T, int MODE>
 static hipError_t launch_conv_t(const Conv3Args& a, hipStream_t s) {
-  const int Ho = MODE == 0 ? a.Hi / 2 : a.Hi * 2, Wo = MODE == 0 ? a.Wi / 2 : a.Wi * 2;
+  const int Ho = MODE == 0 ? a.Hi / 2 : (MODE == 1 ? a.Hi * 2 : a.Hi), Wo = MODE == 0 ? a.Wi / 2 : (MODE == 1 ? a.Wi * 2 : a.Wi);
   if (Ho % 8 || Wo % 8 || a.Cin % 32 || a.Cout % 32 || (MODE == 0 && (a.Hi % 2 || a.Wi % 2))) return hipErrorInvalidValue;
   const int BN = (a.Cout % 128 == 0) ? 128 : ((a.Cout % 64 == 0) ? 64 : 32);
   if (conv_tw(Wo) == 16) {
@@ -632,11 +640,11 @@ static hipError_t launch_conv_t(const Conv3Args& a, hipStream_t s) {
 }
 
 hipError_t launch_conv3x3(int dtype, const Conv3Args& a, hipStream_t s) {
-  if (a.mode != 0 && a.mode != 1) return hipErrorInvalidValue;
+  if (a.mode < 0 || a.mode > 2) return hipErrorInvalidValue;
   switch (dtype) {
-    case 0: return a.mode == 0 ? launch_conv_t<float, 0>(a, s) : launch_conv_t<float, 1>(a, s);
-    case 1: return a.mode == 0 ? launch_conv_t<half_t, 0>(a, s) : launch_conv_t<half_t, 1>(a, s);
-    case 2: return a.mode == 0 ? launch_conv_t<bf16_t, 0>(a, s) : launch_conv_t<bf16_t, 1>(a, s);
+    case 0: return a.mode == 0 ? launch_conv_t<float, 0>(a, s) : (a.mode == 1 ? launch_conv_t<float, 1>(a, s) : launch_conv_t<float, 2>(a, s));
+    case 1: return a.mode == 0 ? launch_conv_t<half_t, 0>(a, s) : (a.mode == 1 ? launch_conv_t<half_t, 1>(a, s) : launch_conv_t<half_t, 2>(a, s));
+    case 2: return a.mode == 0 ? launch_conv_t<bf16_t, 0>(a, s) : (a.mode == 1 ? launch_conv_t<bf16_t, 1>(a, s) : launch_conv_t<bf16_t, 2>(a, s));
   }
   return hipErrorInvalidValue;
 }

@@ -85,7 +85,7 @@ __global__ void __launch_bounds__(8 * TX) dwconv3x3_kernel(const DwArgs a, const
     float f[VEC];
     vec_to_f32<T>(v, f);
 #pragma unroll
-    for (int e = 0; e < VEC; ++e) f[e] = relu6f(f[e] * sc[e] + sh[e]);
+    for (int e = 0; e < VEC; ++e) f[e] = a.no_act ? f[e] * sc[e] + sh[e] : relu6f(f[e] * sc[e] + sh[e]);
     return f32_to_vec<T>(f);
   };
   vec_t zero;

@@ -48,6 +48,11 @@ struct Param {
   bool loaded = false;
   int ndim = 1;
   int64_t shape[4] = {0, 0, 0, 0};     // shape in the reference's state_dict
+  // training: second copy in the layout the input-gradient kernels read (PK_MAT: transposed [cols][rows];
+  // PK_DW: taps flipped; PK_CONV3: [8-tap][I][O]); 0 = none.  goff = offset (floats) in the flat gradient buffer.
+  bool has_t = false;
+  size_t t_off = 0;
+  int64_t goff = 0;
 };
 
 struct IrbW {
@@ -55,14 +60,20 @@ struct IrbW {
   bool skip;
   size_t n1g, n1b, n2g, n2b, w_expand, w_dw, se_w1, se_b1, se_w2, se_b2, w_proj;
   int film_off;  // first row of this block inside the concatenated FiLM projection
+  size_t w_expand_t, w_proj_t, w_dw_flip;  // training copies: [cin][hid], [hid (+cin)][cout], flipped taps
+  int p_first;   // index of this block's first parameter (norm1.weight); the rest follow in registration order
 };
 struct AttnW {
   int c, heads, inner;
   size_t ng, nb, w_qkv, w_out, n2g, n2b;
+  size_t w_qkv_t, w_out_t;
+  int p_first;
 };
 struct ConvW {
   int c;
   size_t w, bias;
+  size_t w_t;
+  int p_first;
 };
 struct Block {
   int kind;  // 0 irb, 1 attn
@@ -120,6 +131,29 @@ struct Tens {
   bool valid = false;
 };
 
+// ---------------------------------------------------------------------------------------------
+// Training tape: what the forward pass leaves in the workspace for the backward pass (offsets).
+struct GnRec { size_t as = 0, ab = 0, mean = 0, rstd = 0; };
+struct IrbRec { int w; Tens x0, x1; bool cat; GnRec n1, n2; Tens h1; size_t h2, gate, sehid, semean; Tens y; };
+struct AttnRec { int w; Tens x; GnRec n1, n2; size_t qkv, kv, ao; int nsplit; Tens tmp, y; };
+struct ConvRec { int w; bool up; Tens x, u, y; };
+struct TapeOp { int kind, idx; };  // kind: 0 irb, 1 attn, 2 conv; idx into the vectors below
+struct Tape {
+  std::vector<IrbRec> irbs;
+  std::vector<AttnRec> attns;
+  std::vector<ConvRec> convs;
+  std::vector<TapeOp> ops;  // forward order
+  // UNet level
+  size_t temb = 0, stemb = 0, film = 0;
+  Tens h0, hlast;
+  GnRec fin;
+  const float* lat = nullptr; const float* cond = nullptr; const int64_t* t = nullptr;
+  int B = 0;
+  const void* ws = nullptr;
+  bool valid = false;
+  void clear() { irbs.clear(); attns.clear(); convs.clear(); ops.clear(); valid = false; }
+};
+
 }  // namespace
 
 struct llie_ctx {
@@ -139,6 +173,9 @@ struct llie_ctx {
   // UNet-level tensors
   size_t t_w1 = 0, t_b1 = 0, t_w3 = 0, t_b3 = 0, freqs = 0, film_w = 0, film_b = 0;
   int film_rows = 0;
+  int64_t grad_numel = 0;
+  Tape tape;           // last training forward (llie_unet_train_forward), read by llie_unet_backward
+  Arena* train_arena = nullptr;  // arena state after that forward; the backward pass continues in it
   size_t init_wp = 0, fin_wp = 0;  // MFMA-packed init / final conv weights (2-byte compute dtypes)
   size_t init_w = 0, init_b = 0, fin_g = 0, fin_b = 0, fin_w = 0, fin_bias = 0;
   // hipGraph cache of llie_enhance launch sequences (key -> executable graph)
@@ -200,36 +237,46 @@ struct Builder {
     int i = 0;
     for (int64_t d : dims) p.shape[i++] = d;
   }
-  size_t mat(const std::string& key, int rows, int cols) {
+  size_t mat(const std::string& key, int rows, int cols, size_t* t_off = nullptr) {
     const size_t o = reserve((size_t)rows * cols * es());
     mat_into(key, rows, cols, o, cols, 0);
+    if (t_off) {
+      *t_off = reserve((size_t)rows * cols * es());
+      c->params.back().has_t = true;
+      c->params.back().t_off = *t_off;
+    }
     return o;
   }
   int add_irb(const std::string& p, int cin, int cout, int T, int e) {
     IrbW w{};
     w.cin = cin; w.cout = cout; w.hid = cin * e; w.sq = std::max(1, (int)(w.hid * 0.25));
     w.skip = cin != cout;
+    w.p_first = (int)c->params.size();
     w.n1g = f32(p + ".norm1.weight", cin); w.n1b = f32(p + ".norm1.bias", cin);
     w.n2g = f32(p + ".norm2.weight", w.hid); w.n2b = f32(p + ".norm2.bias", w.hid);
-    w.w_expand = mat(p + ".expand.weight", w.hid, cin);
+    w.w_expand = mat(p + ".expand.weight", w.hid, cin, &w.w_expand_t);
     w.w_dw = reserve((size_t)9 * w.hid * 4);
-    { Param& q = add(p + ".depthwise.weight", (int64_t)w.hid * 9, PK_DW, w.w_dw); q.O = w.hid; set_shape(q, {w.hid, 1, 3, 3}); }
+    w.w_dw_flip = reserve((size_t)9 * w.hid * 4);
+    { Param& q = add(p + ".depthwise.weight", (int64_t)w.hid * 9, PK_DW, w.w_dw); q.O = w.hid; set_shape(q, {w.hid, 1, 3, 3});
+      q.has_t = true; q.t_off = w.w_dw_flip; }
     w.se_w1 = mat(p + ".se.fc1.weight", w.sq, w.hid); w.se_b1 = f32(p + ".se.fc1.bias", w.sq);
     w.se_w2 = mat(p + ".se.fc2.weight", w.hid, w.sq); w.se_b2 = f32(p + ".se.fc2.bias", w.hid);
     const int kp = w.hid + (w.skip ? cin : 0);  // project and skip share one K-concatenated matrix
     w.w_proj = reserve((size_t)cout * kp * es());
+    w.w_proj_t = reserve((size_t)cout * kp * es());  // [kp][cout]: project rows first, then the skip rows
     mat_into(p + ".project.weight", cout, w.hid, w.w_proj, kp, 0);
+    c->params.back().has_t = true; c->params.back().t_off = w.w_proj_t;
     // FiLM Linear: rows appended to the global [F][T] fp32 table (filled in finish())
     w.film_off = c->film_rows;
     c->film_rows += 2 * w.hid;
     film_keys.push_back({p + ".time_mlp.1", 2 * w.hid, w.film_off});
-    if (w.skip) pending_skip.push_back({p + ".skip.weight", cout, cin, w.w_proj, kp, w.hid});
+    if (w.skip) pending_skip.push_back({p + ".skip.weight", cout, cin, w.w_proj, kp, w.hid, w.w_proj_t + (size_t)w.hid * cout * es()});
     flush_pending();  // registration order: ... project, time_mlp, skip
     c->irbs.push_back(w);
     return (int)c->irbs.size() - 1;
   }
   struct FilmKey { std::string p; int rows, off; };
-  struct SkipKey { std::string key; int rows, cols; size_t off; int ld, col0; };
+  struct SkipKey { std::string key; int rows, cols; size_t off; int ld, col0; size_t t_off; };
   std::vector<FilmKey> film_keys;
   std::vector<SkipKey> pending_skip;
   void flush_pending() {
@@ -240,15 +287,19 @@ struct Builder {
     pw.rows = fk.rows; pw.cols = c->cfg.time_embed_dim; pw.ld = pw.cols; pw.col0 = 0; pw.as_t = false;
     set_shape(pw, {fk.rows, c->cfg.time_embed_dim});  // nn.Linear weight
     add(fk.p + ".bias", fk.rows, PK_F32, 0);
-    for (auto& s : pending_skip) mat_into(s.key, s.rows, s.cols, s.off, s.ld, s.col0);
+    for (auto& s : pending_skip) {
+      mat_into(s.key, s.rows, s.cols, s.off, s.ld, s.col0);
+      c->params.back().has_t = true; c->params.back().t_off = s.t_off;
+    }
     pending_skip.clear();
   }
   int add_attn(const std::string& p, int ch, int heads) {
     AttnW w{};
     w.c = ch; w.heads = heads; w.inner = heads * 32;
+    w.p_first = (int)c->params.size();
     w.ng = f32(p + ".norm.weight", ch); w.nb = f32(p + ".norm.bias", ch);
-    w.w_qkv = mat(p + ".to_qkv.weight", 3 * w.inner, ch);
-    w.w_out = mat(p + ".to_out.0.weight", ch, w.inner);
+    w.w_qkv = mat(p + ".to_qkv.weight", 3 * w.inner, ch, &w.w_qkv_t);
+    w.w_out = mat(p + ".to_out.0.weight", ch, w.inner, &w.w_out_t);
     w.n2g = f32(p + ".to_out.1.weight", ch); w.n2b = f32(p + ".to_out.1.bias", ch);
     c->attns.push_back(w);
     return (int)c->attns.size() - 1;
@@ -256,8 +307,11 @@ struct Builder {
   ConvW add_conv3(const std::string& p, int ch) {
     ConvW w{};
     w.c = ch;
+    w.p_first = (int)c->params.size();
     w.w = reserve((size_t)9 * ch * ch * es());
-    { Param& q = add(p + ".weight", (int64_t)ch * ch * 9, PK_CONV3, w.w); q.O = ch; q.I = ch; set_shape(q, {ch, ch, 3, 3}); }
+    w.w_t = reserve((size_t)9 * ch * ch * es());
+    { Param& q = add(p + ".weight", (int64_t)ch * ch * 9, PK_CONV3, w.w); q.O = ch; q.I = ch; set_shape(q, {ch, ch, 3, 3});
+      q.has_t = true; q.t_off = w.w_t; }
     w.bias = f32(p + ".bias", ch);
     return w;
   }
@@ -273,6 +327,12 @@ struct Builder {
     }
   }
 };
+
+void assign_grad_offsets(llie_ctx* c) {
+  int64_t o = 0;
+  for (Param& p : c->params) { p.goff = o; o += p.numel; }
+  c->grad_numel = o;
+}
 
 int build_unet(llie_ctx* c) {
   const llie_config& g = c->cfg;
@@ -358,6 +418,7 @@ int build_unet(llie_ctx* c) {
   c->freqs = b.reserve((size_t)(g.base_channels / 2) * 4);
   b.finish_film();
   c->blob_bytes = b.cursor;
+  assign_grad_offsets(c);
   return LLIE_OK;
 }
 
@@ -388,6 +449,7 @@ int build_module(llie_ctx* c) {
     c->index[k] = (int)i;
   }
   c->blob_bytes = b.cursor;
+  assign_grad_offsets(c);
   return LLIE_OK;
 }
 
@@ -408,6 +470,8 @@ struct Run {
   int B;
   int dt;
   hipError_t err = hipSuccess;
+  Tape* tape = nullptr;  // non-null: training forward -- nothing is released, every operator is recorded
+  void rel(size_t off) { if (!tape) ar->free(off); }
 
   template <typename T = void> T* wptr(size_t off) const { return reinterpret_cast<T*>(c->blob + off); }
   template <typename T = void> T* p(size_t off) const { return reinterpret_cast<T*>(ws + off); }
@@ -433,7 +497,7 @@ struct Run {
     return t;
   }
   void free_tens(Tens& t) {
-    if (!t.valid) return;
+    if (!t.valid || tape) return;
     ar->free(t.off);
     ar->free(t.slab);
     t.valid = false;
@@ -442,10 +506,16 @@ struct Run {
 
   // GroupNorm affine of (x0 [+ x1]) -> freshly allocated as/ab [B][C]; returns offsets
   void gn(const Tens& x0, const Tens* x1, size_t gamma, size_t beta, const float* film, int64_t film_stride,
-          size_t& as, size_t& ab) {
+          size_t& as, size_t& ab, GnRec* rec = nullptr) {
     const int C = x0.C + (x1 ? x1->C : 0);
     as = ar->alloc((size_t)B * C * 4);
     ab = ar->alloc((size_t)B * C * 4);
+    size_t mo = 0, ro = 0;
+    if (tape && rec) {
+      mo = ar->alloc((size_t)B * 32 * 4);
+      ro = ar->alloc((size_t)B * 32 * 4);
+      rec->as = as; rec->ab = ab; rec->mean = mo; rec->rstd = ro;
+    }
     if (dry) return;
     GnFinalizeArgs a{};
     a.src[0] = src(x0);
@@ -454,6 +524,7 @@ struct Run {
     a.gamma = wptr<float>(gamma); a.beta = wptr<float>(beta);
     a.film = film; a.film_stride = film_stride; a.eps = 1e-5f;
     a.as = p<float>(as); a.ab = p<float>(ab); a.B = B;
+    if (tape && rec) { a.mean_out = p<float>(mo); a.rstd_out = p<float>(ro); }
     chk(launch_gn_finalize(a, s));
   }
 
@@ -462,10 +533,11 @@ struct Run {
     const int H = x0.H, W = x0.W, P = H * W, M = B * P;
     const int BM = pw_gemm_tile_rows(P);
     size_t as1, ab1;
-    gn(x0, x1, w.n1g, w.n1b, nullptr, 0, as1, ab1);
+    IrbRec rec{};
+    gn(x0, x1, w.n1g, w.n1b, nullptr, 0, as1, ab1, &rec.n1);
     // Recompute form (2-byte T, narrow inputs): K1 only produces h1's statistics and the fused
     // expand+depthwise kernel rebuilds h1 on the fly, so the 4x-expanded tensor never touches HBM.
-    const bool fused = g_use_dwx && dwx_supported(dt, w.cin, w.hid, H, W);
+    const bool fused = !tape && g_use_dwx && dwx_supported(dt, w.cin, w.hid, H, W);
     // K1: expand with norm1 + ReLU6 prologue
     Tens h1;
     h1.C = w.hid; h1.H = H; h1.W = W; h1.ntiles = P / BM; h1.valid = true;
@@ -486,7 +558,7 @@ struct Run {
     }
     // norm2 + FiLM folded into one affine
     size_t as2, ab2;
-    gn(h1, nullptr, w.n2g, w.n2b, film ? film + w.film_off : nullptr, film_stride, as2, ab2);
+    gn(h1, nullptr, w.n2g, w.n2b, film ? film + w.film_off : nullptr, film_stride, as2, ab2, &rec.n2);
     // K2: depthwise with affine + ReLU6 prologue and SE pool partials
     const int dnt = dwconv_ntiles(H, W);
     const size_t h2 = ar->alloc((size_t)M * w.hid * es());
@@ -506,10 +578,10 @@ struct Run {
         timed(LLIE_K_DW, 2LL * M * w.hid * (int64_t)es(), [&] { return launch_dwconv3x3(dt, d, s); });
       }
     }
-    ar->free(as1); ar->free(ab1);
-    if (!fused) ar->free(h1.off);
-    ar->free(h1.slab);
-    ar->free(as2); ar->free(ab2);
+    rel(as1); rel(ab1);
+    if (!fused) rel(h1.off);
+    rel(h1.slab);
+    rel(as2); rel(ab2);
     // SE MLP
     const size_t sehid = ar->alloc((size_t)B * w.sq * 4), gate = ar->alloc((size_t)B * w.hid * 4);
     const size_t semean = ar->alloc((size_t)B * w.hid * 4);
@@ -523,7 +595,7 @@ struct Run {
         return r1 != hipSuccess ? r1 : launch_se_fc2(dt, e, s);
       });
     }
-    ar->free(pool); ar->free(sehid); ar->free(semean);
+    rel(pool); rel(sehid); rel(semean);
     // K3: project with SE gate prologue (+ skip conv as extra K segments, or identity residual)
     Tens y = new_tens(w.cout, H, W, P / BM);
     if (!dry) {
@@ -543,7 +615,15 @@ struct Run {
       timed(LLIE_K_GEMM, ((int64_t)M * (g.K + w.cout + (w.skip ? 0 : w.cout)) + (int64_t)w.cout * g.K) * (int64_t)es(),
             [&] { return launch_pw_gemm(dt, g, s); });
     }
-    ar->free(h2); ar->free(gate);
+    rel(h2); rel(gate);
+    if (tape) {
+      rec.w = (int)(&w - c->irbs.data());
+      rec.x0 = x0; rec.cat = x1 != nullptr;
+      if (x1) rec.x1 = *x1;
+      rec.h1 = h1; rec.h2 = h2; rec.gate = gate; rec.sehid = sehid; rec.semean = semean; rec.y = y;
+      tape->ops.push_back({0, (int)tape->irbs.size()});
+      tape->irbs.push_back(rec);
+    }
     return y;
   }
 
@@ -552,7 +632,8 @@ struct Run {
     const int H = x.H, W = x.W, N = H * W, M = B * N;
     const int BM = pw_gemm_tile_rows(N);
     size_t as, ab;
-    gn(x, nullptr, w.ng, w.nb, nullptr, 0, as, ab);
+    AttnRec rec{};
+    gn(x, nullptr, w.ng, w.nb, nullptr, 0, as, ab, &rec.n1);
     const size_t qkv = ar->alloc((size_t)M * 3 * w.inner * es());
     if (!dry) {
       GemmArgs g{};
@@ -561,7 +642,7 @@ struct Run {
       g.M = M; g.N = 3 * w.inner; g.K = x.C; g.P = N;
       chk(launch_pw_gemm(dt, g, s));
     }
-    ar->free(as); ar->free(ab);
+    rel(as); rel(ab);
     const int nsplit = linattn_nsplit(N);
     const size_t kv = ar->alloc((size_t)nsplit * B * w.heads * 32 * 33 * 4);
     const size_t ao = ar->alloc((size_t)M * w.inner * es());
@@ -571,7 +652,7 @@ struct Run {
       chk(launch_linattn_kv(dt, a, s));
       chk(launch_linattn_out(dt, a, s));
     }
-    ar->free(qkv); ar->free(kv);
+    rel(qkv); rel(kv);
     Tens tmp = new_tens(x.C, H, W, N / BM);
     if (!dry) {
       GemmArgs g{};
@@ -580,9 +661,9 @@ struct Run {
       g.M = M; g.N = x.C; g.K = w.inner; g.P = N;
       chk(launch_pw_gemm(dt, g, s));
     }
-    ar->free(ao);
+    rel(ao);
     size_t as2, ab2;
-    gn(tmp, nullptr, w.n2g, w.n2b, nullptr, 0, as2, ab2);
+    gn(tmp, nullptr, w.n2g, w.n2b, nullptr, 0, as2, ab2, &rec.n2);
     Tens y = new_tens(x.C, H, W, N / kAffineTileRows);
     if (!dry) {
       AffineAddArgs a{};
@@ -591,19 +672,44 @@ struct Run {
       chk(launch_affine_add(dt, a, s));
     }
     free_tens(tmp);
-    ar->free(as2); ar->free(ab2);
+    rel(as2); rel(ab2);
+    if (tape) {
+      rec.w = (int)(&w - c->attns.data());
+      rec.x = x; rec.qkv = qkv; rec.kv = kv; rec.ao = ao; rec.nsplit = nsplit; rec.tmp = tmp; rec.y = y;
+      tape->ops.push_back({1, (int)tape->attns.size()});
+      tape->attns.push_back(rec);
+    }
     return y;
   }
 
   Tens conv3(const ConvW& w, const Tens& x, int mode) {
     const int Ho = mode == 0 ? x.H / 2 : x.H * 2, Wo = mode == 0 ? x.W / 2 : x.W * 2;
     Tens y = new_tens(w.c, Ho, Wo, conv3x3_ntiles(Ho, Wo));
-    if (!dry) {
+    Tens u;
+    if (tape && mode == 1) {
+      // training: keep the upsampled tensor (the weight gradient reads it) and run the plain stride-1 conv on it
+      u.C = w.c; u.H = Ho; u.W = Wo; u.valid = true;
+      u.off = ar->alloc((size_t)B * Ho * Wo * w.c * es());
+      if (!dry) {
+        chk(launch_upsample2x(dt, p(x.off), p(u.off), B, x.H, x.W, w.c, s));
+        Conv3Args a{};
+        a.in = p(u.off); a.w = wptr(w.w); a.bias = wptr<float>(w.bias); a.out = p(y.off); a.stats = p<float>(y.slab);
+        a.B = B; a.Hi = Ho; a.Wi = Wo; a.Cin = w.c; a.Cout = w.c; a.mode = 2;
+        chk(launch_conv3x3(dt, a, s));
+      }
+    } else if (!dry) {
       Conv3Args a{};
       a.in = p(x.off); a.w = wptr(w.w); a.bias = wptr<float>(w.bias); a.out = p(y.off); a.stats = p<float>(y.slab);
       a.B = B; a.Hi = x.H; a.Wi = x.W; a.Cin = w.c; a.Cout = w.c; a.mode = mode;
       timed(LLIE_K_CONV3, ((int64_t)B * w.c * ((int64_t)x.H * x.W + (int64_t)Ho * Wo) + 9LL * w.c * w.c) * (int64_t)es(),
             [&] { return launch_conv3x3(dt, a, s); });
+    }
+    if (tape) {
+      ConvRec rec{};
+      rec.w = mode == 0 ? (int)(&w - c->downs.data()) : (int)(&w - c->ups.data());
+      rec.up = mode != 0; rec.x = x; rec.u = u; rec.y = y;
+      tape->ops.push_back({2, (int)tape->convs.size()});
+      tape->convs.push_back(rec);
     }
     return y;
   }
@@ -653,6 +759,10 @@ struct Run {
       a.B = B; a.H = S; a.W = S; a.Cout = c->channels[0];
       chk(launch_init_conv(dt, a, s));
     }
+    if (tape) {
+      tape->temb = temb; tape->stemb = stemb; tape->film = film; tape->h0 = h;
+      tape->lat = lat; tape->cond = cond; tape->t = t; tape->B = B;
+    }
     Tens skips[4];
     for (int l = 0; l < 4; ++l) {
       h = run_blocks(c->enc[l], h, nullptr, filmp, fstride, false);
@@ -672,7 +782,9 @@ struct Run {
       h = y;
     }
     size_t as, ab;
-    gn(h, nullptr, c->fin_g, c->fin_b, nullptr, 0, as, ab);
+    GnRec finrec{};
+    gn(h, nullptr, c->fin_g, c->fin_b, nullptr, 0, as, ab, &finrec);
+    if (tape) { tape->fin = finrec; tape->hlast = h; }
     if (!dry) {
       FinalConvArgs a{};
       a.in = p(h.off); a.as = p<float>(as); a.ab = p<float>(ab); a.w = wptr<float>(c->fin_w); a.bias = wptr<float>(c->fin_bias);
@@ -684,8 +796,8 @@ struct Run {
       chk(launch_final_conv(dt, a, s));
     }
     free_tens(h);
-    ar->free(as); ar->free(ab);
-    ar->free(temb); ar->free(stemb); ar->free(film);
+    rel(as); rel(ab);
+    rel(temb); rel(stemb); rel(film);
   }
 
   // single-operator forward: fp32 NCHW in/out
@@ -712,7 +824,8 @@ struct Run {
         chk(launch_film(fa, s));
       }
       out = irb(c->irbs[0], x0, split ? &x1 : nullptr, p<float>(film), F);
-      ar->free(st); ar->free(film);
+      rel(st); rel(film);
+      if (tape) { tape->stemb = st; tape->film = film; }
     } else if (g.kind == LLIE_ATTN) {
       out = attn(c->attns[0], x0);
     } else if (g.kind == LLIE_DOWN) {
@@ -720,10 +833,425 @@ struct Run {
     } else {
       out = conv3(c->ups[0], x0, 1);
     }
-    if (!dry) chk(launch_nhwc_to_nchw(dt, p(out.off), y, B, out.C, out.H * out.W, s));
+    if (!dry && y) chk(launch_nhwc_to_nchw(dt, p(out.off), y, B, out.C, out.H * out.W, s));
+    if (tape) { tape->h0 = x0; tape->hlast = out; tape->B = B; mod_x1 = x1; }
     free_tens(out);
     free_tens(x0);
     free_tens(x1);
+  }
+  Tens mod_x1;  // training, IRB module with a virtual-concat input: the second segment
+};
+
+// ---------------------------------------------------------------------------------------------
+// Backward pass over the tape.  Reverse-mode over the recorded operators: every forward
+// tensor's gradient lives in the same workspace (NHWC T), keyed by the tensor's offset; an operator takes
+// the gradient of its output, writes / accumulates the gradients of its inputs and the fp32 parameter
+// gradients (reference state_dict layout, flat buffer `grads` at Param::goff).
+struct Back {
+  llie_ctx* c;
+  Arena* ar;
+  hipStream_t s;
+  char* ws;
+  bool dry;
+  int B;
+  int dt;
+  Tape* tp;
+  float* grads;
+  hipError_t err = hipSuccess;
+  std::map<size_t, size_t> gmap;  // forward tensor offset -> gradient offset
+
+  template <typename T = void> T* wptr(size_t off) const { return reinterpret_cast<T*>(c->blob + off); }
+  template <typename T = void> T* p(size_t off) const { return reinterpret_cast<T*>(ws + off); }
+  void chk(hipError_t e) { if (e != hipSuccess && err == hipSuccess) err = e; }
+  size_t es() const { return elem_size(dt); }
+  size_t alloc(size_t bytes) { return ar->alloc(bytes); }
+  float* gp(int param) const { return grads + c->params[param].goff; }
+  int pidx(const char* key) const { return c->index.at(key); }
+
+  size_t take_grad(const Tens& t) {
+    auto it = gmap.find(t.off);
+    if (it == gmap.end()) { if (err == hipSuccess) err = hipErrorInvalidValue; return 0; }
+    const size_t g = it->second;
+    gmap.erase(it);
+    return g;
+  }
+  // gradient buffer of a forward tensor: the existing one (existed = true) or a fresh allocation
+  size_t grad_of(const Tens& t, bool& existed) {
+    auto it = gmap.find(t.off);
+    existed = it != gmap.end();
+    if (existed) return it->second;
+    const size_t g = alloc((size_t)B * t.H * t.W * t.C * es());
+    gmap[t.off] = g;
+    return g;
+  }
+  void add_grad(const Tens& t, size_t g) {  // hand over `g` as (part of) t's gradient
+    auto it = gmap.find(t.off);
+    if (it == gmap.end()) { gmap[t.off] = g; return; }
+    if (!dry) chk(launch_add_into(dt, p(it->second), p(g), (int64_t)B * t.H * t.W * t.C, s));
+    ar->free(g);
+  }
+
+  // out[M][N] = in[M][K] * W[N][K]^T on the forward GEMM kernel (W = a transposed weight copy)
+  void gemm(size_t in, int K, const void* w, size_t out, int N, int M, int P) {
+    if (dry) return;
+    GemmArgs g{};
+    g.seg[0] = GemmSeg{p(in), K, nullptr, nullptr, 0, ACT_NONE};
+    g.nseg = 1; g.w = w; g.out = p(out); g.M = M; g.N = N; g.K = K; g.P = P;
+    chk(launch_pw_gemm(dt, g, s));
+  }
+  struct Geo { int Ho, Wo, Hi, Wi, stride, dy, dx; };
+  void wgrad(size_t g, int N, const GemmSeg* segs, int nseg, int K, Geo geo, float* out, int64_t ldn, int64_t ldk, int64_t off) {
+    const int M = B * geo.Ho * geo.Wo;
+    const int ms = wgrad_msplit(M, N, K);
+    const size_t part = alloc((size_t)ms * N * K * 4);
+    if (!dry) {
+      WgradArgs a{};
+      a.g = p(g); a.N = N; a.nseg = nseg; a.K = K;
+      for (int i = 0; i < nseg; ++i) a.seg[i] = segs[i];
+      a.B = B; a.Ho = geo.Ho; a.Wo = geo.Wo; a.Hi = geo.Hi; a.Wi = geo.Wi; a.stride = geo.stride; a.dy = geo.dy; a.dx = geo.dx;
+      a.partial = p<float>(part); a.out = out; a.ldn = ldn; a.ldk = ldk; a.off = off; a.msplit = ms;
+      chk(launch_wgrad(dt, a, s));
+    }
+    ar->free(part);
+  }
+
+  // activation backward + GroupNorm backward coefficients + norm parameter gradients at one norm site.
+  //   g: gradient w.r.t. the activation output act(norm(x)) [M][C]; dz is written over g when act != none.
+  struct Coef { size_t A, Bq, Cq; };
+  Coef gn_site(size_t g, const Tens& x0, const Tens* x1, const GnRec& rec, int act, size_t gamma, size_t beta,
+               float* dgamma, float* dbeta, const float* film, int64_t fstride, float* dfilm, int64_t dfstride) {
+    const int C = x0.C + (x1 ? x1->C : 0), P = x0.H * x0.W, M = B * P, nt = P / 64;
+    const size_t slab = alloc((size_t)B * nt * 2 * C * 4), S = alloc((size_t)B * 2 * C * 4);
+    Coef k{alloc((size_t)B * C * 4), alloc((size_t)B * C * 4), alloc((size_t)B * C * 4)};
+    const size_t dG = alloc((size_t)B * C * 4), dBc = alloc((size_t)B * C * 4);
+    if (!dry) {
+      BwdMaskArgs m{};
+      m.g = p(g); m.x0 = p(x0.off); m.c0 = x0.C; m.x1 = x1 ? p(x1->off) : nullptr; m.c1 = x1 ? x1->C : 0;
+      m.as = p<float>(rec.as); m.ab = p<float>(rec.ab); m.act = act; m.dz = act == ACT_NONE ? nullptr : p(g);
+      m.slab = p<float>(slab); m.M = M; m.C = C; m.P = P;
+      chk(launch_bwd_mask_reduce(dt, m, s));
+      chk(launch_slab_reduce(p<float>(slab), p<float>(S), B, nt, 2, 2, C, s));
+      GnBwdArgs a{};
+      a.S = p<float>(S); a.mean = p<float>(rec.mean); a.rstd = p<float>(rec.rstd); a.gamma = wptr<float>(gamma);
+      a.film = film; a.film_stride = fstride; a.C = C; a.groups = 32; a.P = P; a.B = B;
+      a.A = p<float>(k.A); a.Bq = p<float>(k.Bq); a.Cq = p<float>(k.Cq); a.dG = p<float>(dG); a.dBc = p<float>(dBc);
+      chk(launch_gn_bwd_coef(a, s));
+      GnParamGradArgs q{};
+      q.dG = p<float>(dG); q.dBc = p<float>(dBc); q.gamma = wptr<float>(gamma); q.beta = wptr<float>(beta);
+      q.film = film; q.film_stride = fstride; q.dgamma = dgamma; q.dbeta = dbeta; q.dfilm = dfilm; q.dfilm_stride = dfstride;
+      q.B = B; q.C = C;
+      chk(launch_gn_param_grad(q, s));
+    }
+    ar->free(slab); ar->free(S); ar->free(dG); ar->free(dBc);
+    return k;
+  }
+  void free_coef(const Coef& k) { ar->free(k.A); ar->free(k.Bq); ar->free(k.Cq); }
+  void apply(size_t dz, const Tens& x0, const Tens* x1, const Coef& k, size_t add0, bool has_add0, size_t a10, bool has10,
+             size_t a11, bool has11, size_t dx0, size_t dx1) {
+    if (dry) return;
+    GnApplyArgs a{};
+    a.dz = p(dz); a.x0 = p(x0.off); a.c0 = x0.C; a.x1 = x1 ? p(x1->off) : nullptr; a.c1 = x1 ? x1->C : 0;
+    a.A = p<float>(k.A); a.Bq = p<float>(k.Bq); a.Cq = p<float>(k.Cq);
+    a.add0 = has_add0 ? p(add0) : nullptr; a.add1_0 = has10 ? p(a10) : nullptr; a.add1_1 = has11 ? p(a11) : nullptr;
+    a.dx0 = p(dx0); a.dx1 = x1 ? p(dx1) : nullptr; a.M = B * x0.H * x0.W; a.P = x0.H * x0.W;
+    chk(launch_gn_bwd_apply(dt, a, s));
+  }
+
+  // ---- InvertedResidualBlock
+  void irb_bwd(const IrbRec& r, size_t dfilm, int F) {
+    const IrbW& w = c->irbs[r.w];
+    const int H = r.x0.H, W = r.x0.W, P = H * W, M = B * P, hid = w.hid, cin = w.cin, cout = w.cout, pf = w.p_first;
+    const Tens* x1 = r.cat ? &r.x1 : nullptr;
+    const size_t dY = take_grad(r.y);
+    const Geo g11{H, W, H, W, 1, 0, 0};
+    // project (+ skip) input gradients
+    const size_t da3 = alloc((size_t)M * hid * es());
+    gemm(dY, cout, wptr(w.w_proj_t), da3, hid, M, P);
+    size_t dxs = 0;
+    if (w.skip) {
+      dxs = alloc((size_t)M * cin * es());
+      gemm(dY, cout, wptr<char>(w.w_proj_t) + (size_t)hid * cout * es(), dxs, cin, M, P);
+    }
+    {  // project / skip weight gradients
+      GemmSeg sg[2];
+      sg[0] = GemmSeg{dry ? nullptr : p(r.h2), hid, dry ? nullptr : p<float>(r.gate), nullptr, hid, ACT_NONE};
+      wgrad(dY, cout, sg, 1, hid, g11, gp(pf + 10), hid, 1, 0);
+      if (w.skip) {
+        sg[0] = GemmSeg{dry ? nullptr : p(r.x0.off), r.x0.C, nullptr, nullptr, 0, ACT_NONE};
+        if (x1) sg[1] = GemmSeg{dry ? nullptr : p(x1->off), x1->C, nullptr, nullptr, 0, ACT_NONE};
+        wgrad(dY, cout, sg, x1 ? 2 : 1, cin, g11, gp(pf + 13), cin, 1, 0);
+      }
+    }
+    // SE: dgate = sum_px da3*h2, then the two-layer MLP backwards to d(mean)
+    const size_t dgate = alloc((size_t)B * hid * 4), dpre2 = alloc((size_t)B * hid * 4), dr = alloc((size_t)B * w.sq * 4);
+    const size_t dmean = alloc((size_t)B * hid * 4);
+    {
+      const int nt = P / 64;
+      const size_t slab = alloc((size_t)B * nt * 2 * hid * 4);
+      if (!dry) {
+        BwdMaskArgs m{};
+        m.g = p(da3); m.x0 = p(r.h2); m.c0 = hid; m.act = ACT_NONE; m.slab = p<float>(slab); m.M = M; m.C = hid; m.P = P;
+        chk(launch_bwd_mask_reduce(dt, m, s));
+        chk(launch_slab_reduce(p<float>(slab) + hid, p<float>(dgate), B, nt, 2, 1, hid, s));
+        chk(launch_sigmoid_bwd(p<float>(dgate), p<float>(r.gate), p<float>(dpre2), (int64_t)B * hid, s));
+        chk(launch_linear_dw(p<float>(dpre2), hid, p<float>(r.sehid), gp(pf + 8), gp(pf + 9), B, hid, w.sq, s));
+        chk(launch_linear_dx(dt, p<float>(dpre2), hid, wptr(w.se_w2), p<float>(dr), B, hid, w.sq, s));
+        chk(launch_relu6_bwd(p<float>(dr), p<float>(r.sehid), p<float>(dr), (int64_t)B * w.sq, s));
+        chk(launch_linear_dw(p<float>(dr), w.sq, p<float>(r.semean), gp(pf + 6), gp(pf + 7), B, w.sq, hid, s));
+        chk(launch_linear_dx(dt, p<float>(dr), w.sq, wptr(w.se_w1), p<float>(dmean), B, w.sq, hid, s));
+        chk(launch_scale_rows(p<float>(dmean), p<float>(dmean), (int64_t)B * hid, 1.f / (float)P, s));
+      }
+      ar->free(slab);
+    }
+    // depthwise: input gradient (same kernel, flipped taps, prologue dh2 = da3*gate + dmean/P) and weight gradient
+    const size_t da2 = alloc((size_t)M * hid * es());
+    {
+      const size_t part = alloc((size_t)B * dw_wgrad_strips(H, W) * 9 * hid * 4);
+      if (!dry) {
+        DwArgs d{};
+        d.in = p(da3); d.out = p(da2); d.as = p<float>(r.gate); d.ab = p<float>(dmean); d.w = wptr<float>(w.w_dw_flip);
+        d.pool = nullptr; d.B = B; d.H = H; d.W = W; d.C = hid; d.no_act = 1;
+        chk(launch_dwconv3x3(dt, d, s));
+        DwWgradArgs q{};
+        q.g = p(da3); q.gs = p<float>(r.gate); q.gb = p<float>(dmean); q.h = p(r.h1.off); q.as = p<float>(r.n2.as);
+        q.ab = p<float>(r.n2.ab); q.partial = p<float>(part); q.out = gp(pf + 5); q.B = B; q.H = H; q.W = W; q.C = hid;
+        chk(launch_dw_wgrad(dt, q, s));
+      }
+      ar->free(part);
+    }
+    ar->free(da3); ar->free(dgate); ar->free(dpre2); ar->free(dr); ar->free(dmean);
+    // norm2 + FiLM + ReLU6
+    const float* film = dry ? nullptr : p<float>(tp->film) + w.film_off;
+    float* dfl = dry ? nullptr : p<float>(dfilm) + w.film_off;
+    Coef k2 = gn_site(da2, r.h1, nullptr, r.n2, ACT_RELU6, w.n2g, w.n2b, gp(pf + 2), gp(pf + 3), film, F, dfl, F);
+    apply(da2, r.h1, nullptr, k2, 0, false, 0, false, 0, false, da2, 0);  // dh1, in place
+    free_coef(k2);
+    // expand
+    const size_t da1 = alloc((size_t)M * cin * es());
+    gemm(da2, hid, wptr(w.w_expand_t), da1, cin, M, P);
+    {
+      GemmSeg sg[2];
+      sg[0] = GemmSeg{dry ? nullptr : p(r.x0.off), r.x0.C, dry ? nullptr : p<float>(r.n1.as), dry ? nullptr : p<float>(r.n1.ab), cin, ACT_RELU6};
+      if (x1) sg[1] = GemmSeg{dry ? nullptr : p(x1->off), x1->C, dry ? nullptr : p<float>(r.n1.as) + r.x0.C,
+                              dry ? nullptr : p<float>(r.n1.ab) + r.x0.C, cin, ACT_RELU6};
+      wgrad(da2, hid, sg, x1 ? 2 : 1, cin, g11, gp(pf + 4), cin, 1, 0);
+    }
+    ar->free(da2);
+    // norm1 + ReLU6, then the block input (residual / skip-conv gradient added, existing gradients accumulated)
+    Coef k1 = gn_site(da1, r.x0, x1, r.n1, ACT_RELU6, w.n1g, w.n1b, gp(pf + 0), gp(pf + 1), nullptr, 0, nullptr, 0);
+    bool e0 = false, e1 = false;
+    const size_t g0 = grad_of(r.x0, e0);
+    const size_t g1 = x1 ? grad_of(*x1, e1) : 0;
+    apply(da1, r.x0, x1, k1, w.skip ? dxs : dY, true, g0, e0, g1, e1, g0, g1);
+    free_coef(k1);
+    ar->free(da1);
+    if (w.skip) ar->free(dxs);
+    ar->free(dY);
+  }
+
+  // ---- LinearAttention
+  void attn_bwd(const AttnRec& r) {
+    const AttnW& w = c->attns[r.w];
+    const int H = r.x.H, W = r.x.W, N = H * W, M = B * N, C = w.c, inner = w.inner, pf = w.p_first;
+    const size_t dY = take_grad(r.y);
+    const Geo g11{H, W, H, W, 1, 0, 0};
+    // y = norm2(tmp) + x
+    Coef k2 = gn_site(dY, r.tmp, nullptr, r.n2, ACT_NONE, w.n2g, w.n2b, gp(pf + 4), gp(pf + 5), nullptr, 0, nullptr, 0);
+    const size_t dtmp = alloc((size_t)M * C * es());
+    apply(dY, r.tmp, nullptr, k2, 0, false, 0, false, 0, false, dtmp, 0);
+    free_coef(k2);
+    // to_out
+    const size_t dao = alloc((size_t)M * inner * es());
+    gemm(dtmp, C, wptr(w.w_out_t), dao, inner, M, N);
+    {
+      GemmSeg sg{dry ? nullptr : p(r.ao), inner, nullptr, nullptr, 0, ACT_NONE};
+      wgrad(dtmp, C, &sg, 1, inner, g11, gp(pf + 3), inner, 1, 0);
+    }
+    ar->free(dtmp);
+    // attention core
+    const size_t dqkv = alloc((size_t)M * 3 * inner * es());
+    {
+      const int nt = N / 64;
+      const size_t part = alloc((size_t)B * w.heads * nt * 32 * 33 * 4), tot = alloc((size_t)B * w.heads * 32 * 33 * 4);
+      if (!dry) {
+        AttnBwdArgs a{};
+        a.qkv = p(r.qkv); a.dout = p(dao); a.dqkv = p(dqkv); a.kv = p<float>(r.kv); a.nsplit = r.nsplit;
+        a.dkv = p<float>(part); a.B = B; a.N = N; a.heads = w.heads;
+        chk(launch_linattn_bwd_q(dt, a, s));
+        chk(launch_slab_reduce(p<float>(part), p<float>(tot), B * w.heads, nt, 1, 1, 32 * 33, s));
+        a.dkv = p<float>(tot);
+        chk(launch_linattn_bwd_kv(dt, a, s));
+      }
+      ar->free(part); ar->free(tot);
+    }
+    ar->free(dao);
+    // to_qkv
+    const size_t dxn = alloc((size_t)M * C * es());
+    gemm(dqkv, 3 * inner, wptr(w.w_qkv_t), dxn, C, M, N);
+    {
+      GemmSeg sg{dry ? nullptr : p(r.x.off), C, dry ? nullptr : p<float>(r.n1.as), dry ? nullptr : p<float>(r.n1.ab), C, ACT_NONE};
+      wgrad(dqkv, 3 * inner, &sg, 1, C, g11, gp(pf + 2), C, 1, 0);
+    }
+    ar->free(dqkv);
+    // norm (no activation) + residual
+    Coef k1 = gn_site(dxn, r.x, nullptr, r.n1, ACT_NONE, w.ng, w.nb, gp(pf + 0), gp(pf + 1), nullptr, 0, nullptr, 0);
+    bool e0 = false;
+    const size_t g0 = grad_of(r.x, e0);
+    apply(dxn, r.x, nullptr, k1, dY, true, g0, e0, 0, false, g0, 0);
+    free_coef(k1);
+    ar->free(dxn);
+    ar->free(dY);
+  }
+
+  // ---- Downsample / Upsample convolutions
+  void conv_bwd(const ConvRec& r) {
+    const ConvW& w = r.up ? c->ups[r.w] : c->downs[r.w];
+    const int C = w.c, Ho = r.y.H, Wo = r.y.W, Mo = B * Ho * Wo, pf = w.p_first;
+    const size_t dY = take_grad(r.y);
+    {  // bias gradient: column sums of dY
+      const int nt = Ho * Wo / 64;
+      const size_t slab = alloc((size_t)B * nt * 2 * C * 4), S = alloc((size_t)B * C * 4);
+      if (!dry) {
+        BwdMaskArgs m{};
+        m.g = p(dY); m.act = ACT_NONE; m.slab = p<float>(slab); m.M = Mo; m.C = C; m.P = Ho * Wo;
+        chk(launch_bwd_mask_reduce(dt, m, s));
+        chk(launch_slab_reduce(p<float>(slab), p<float>(S), B, nt, 2, 1, C, s));
+        chk(launch_batch_sum(p<float>(S), gp(pf + 1), B, C, C, s));
+      }
+      ar->free(slab); ar->free(S);
+    }
+    const Tens& src = r.up ? r.u : r.x;  // what the conv itself read
+    for (int tap = 0; tap < 9; ++tap) {
+      GemmSeg sg{dry ? nullptr : p(src.off), C, nullptr, nullptr, 0, ACT_NONE};
+      const Geo geo{Ho, Wo, src.H, src.W, r.up ? 1 : 2, tap / 3 - 1, tap % 3 - 1};
+      wgrad(dY, C, &sg, 1, C, geo, gp(pf + 0), (int64_t)C * 9, 9, tap);
+    }
+    // input gradient: stride-1 conv with flipped / transposed weights over dY (zero-dilated for the stride-2 conv)
+    size_t din = dY;
+    if (!r.up) {
+      din = alloc((size_t)B * r.x.H * r.x.W * C * es());
+      if (!dry) chk(launch_dilate2x(dt, p(dY), p(din), B, Ho, Wo, C, s));
+    }
+    const size_t dsrc = alloc((size_t)B * src.H * src.W * C * es());
+    if (!dry) {
+      Conv3Args a{};
+      a.in = p(din); a.w = wptr(w.w_t); a.bias = nullptr; a.out = p(dsrc); a.stats = nullptr;
+      a.B = B; a.Hi = src.H; a.Wi = src.W; a.Cin = C; a.Cout = C; a.mode = 2;
+      chk(launch_conv3x3(dt, a, s));
+    }
+    if (!r.up) ar->free(din);
+    ar->free(dY);
+    if (r.up) {
+      const size_t dx = alloc((size_t)B * r.x.H * r.x.W * C * es());
+      if (!dry) chk(launch_upsample2x_bwd(dt, p(dsrc), p(dx), B, r.x.H, r.x.W, C, s));
+      ar->free(dsrc);
+      add_grad(r.x, dx);
+    } else {
+      add_grad(r.x, dsrc);
+    }
+  }
+
+  void run_ops(size_t dfilm, int F) {
+    for (int i = (int)tp->ops.size() - 1; i >= 0; --i) {
+      const TapeOp& op = tp->ops[i];
+      if (op.kind == 0) irb_bwd(tp->irbs[op.idx], dfilm, F);
+      else if (op.kind == 1) attn_bwd(tp->attns[op.idx]);
+      else conv_bwd(tp->convs[op.idx]);
+    }
+  }
+  // FiLM Linear of every block: weight / bias gradients, and d(silu(temb)) summed over all FiLM rows
+  void film_bwd(size_t dfilm, int F, int T, size_t dstemb) {
+    if (dry) return;
+    for (const IrbW& w : c->irbs)
+      chk(launch_linear_dw(p<float>(dfilm) + w.film_off, F, p<float>(tp->stemb), gp(w.p_first + 11), gp(w.p_first + 12), B,
+                           2 * w.hid, T, s));
+    chk(launch_linear_dx(0, p<float>(dfilm), F, wptr(c->film_w), p<float>(dstemb), B, F, T, s));
+  }
+
+  // ---- whole UNet
+  void unet(const float* deps) {
+    const llie_config& g = c->cfg;
+    const int S = g.image_size, C0 = c->channels[0], P = S * S, M = B * P, T = g.time_embed_dim, F = c->film_rows;
+    const size_t dfilm = alloc((size_t)B * F * 4);
+    // output head
+    const size_t da = alloc((size_t)M * C0 * es());
+    {
+      const size_t part = alloc((size_t)B * (S / 8) * (g.out_channels * 9 + 1) * C0 * 4);
+      if (!dry) {
+        FinalBwdArgs a{};
+        a.deps = deps; a.w = wptr<float>(c->fin_w); a.h = p(tp->hlast.off); a.as = p<float>(tp->fin.as); a.ab = p<float>(tp->fin.ab);
+        a.da = p(da); a.partial = p<float>(part); a.dw = gp(pidx("final_conv.weight")); a.dbias = gp(pidx("final_conv.bias"));
+        a.B = B; a.H = S; a.W = S; a.C = C0; a.Cout = g.out_channels;
+        chk(launch_final_bwd_data(dt, a, s));
+        chk(launch_final_bwd_weight(dt, a, s));
+      }
+      ar->free(part);
+    }
+    Coef kf = gn_site(da, tp->hlast, nullptr, tp->fin, ACT_SILU, c->fin_g, c->fin_b, gp(pidx("final_norm.weight")),
+                      gp(pidx("final_norm.bias")), nullptr, 0, nullptr, 0);
+    apply(da, tp->hlast, nullptr, kf, 0, false, 0, false, 0, false, da, 0);
+    free_coef(kf);
+    gmap[tp->hlast.off] = da;
+    run_ops(dfilm, F);
+    // input conv
+    {
+      const size_t g0 = take_grad(tp->h0);
+      const int half = g.in_channels / 2;
+      const size_t part = alloc((size_t)B * (S / 8) * (g.in_channels * 9 + 1) * C0 * 4);
+      if (!dry) {
+        InitBwdArgs a{};
+        a.g = p(g0); a.x0 = tp->lat; a.x1 = tp->cond; a.c0 = half; a.c1 = g.in_channels - half; a.partial = p<float>(part);
+        a.dw = gp(pidx("init_conv.weight")); a.dbias = gp(pidx("init_conv.bias")); a.B = B; a.H = S; a.W = S; a.Cout = C0;
+        chk(launch_init_bwd_weight(dt, a, s));
+      }
+      ar->free(part); ar->free(g0);
+    }
+    // time embedding MLP (efficient_unet.py:412-417): temb = W3 silu(W1 emb + b1) + b3, FiLM reads silu(temb)
+    const int dim = g.base_channels;
+    const size_t dtemb = alloc((size_t)B * T * 4), emb = alloc((size_t)B * dim * 4), z1 = alloc((size_t)B * T * 4);
+    const size_t a1 = alloc((size_t)B * T * 4), dh = alloc((size_t)B * T * 4);
+    film_bwd(dfilm, F, T, dtemb);
+    if (!dry) {
+      chk(launch_silu_bwd(p<float>(dtemb), p<float>(tp->temb), p<float>(dtemb), (int64_t)B * T, s));
+      chk(launch_sin_embed(tp->t, wptr<float>(c->freqs), p<float>(emb), B, dim, s));
+      FilmArgs fa{};
+      fa.silu_temb = p<float>(emb); fa.rows = B; fa.T = dim; fa.wf = wptr<float>(c->t_w1); fa.bf = wptr<float>(c->t_b1);
+      fa.film = p<float>(z1); fa.F = T;
+      chk(launch_film(fa, s));
+      chk(launch_silu_rows(p<float>(z1), p<float>(a1), (int64_t)B * T, s));
+      chk(launch_linear_dw(p<float>(dtemb), T, p<float>(a1), gp(pidx("time_mlp.3.weight")), gp(pidx("time_mlp.3.bias")), B, T, T, s));
+      chk(launch_linear_dx(0, p<float>(dtemb), T, wptr(c->t_w3), p<float>(dh), B, T, T, s));
+      chk(launch_silu_bwd(p<float>(dh), p<float>(z1), p<float>(dh), (int64_t)B * T, s));
+      chk(launch_linear_dw(p<float>(dh), T, p<float>(emb), gp(pidx("time_mlp.1.weight")), gp(pidx("time_mlp.1.bias")), B, T, dim, s));
+    }
+    ar->free(dtemb); ar->free(emb); ar->free(z1); ar->free(a1); ar->free(dh); ar->free(dfilm);
+  }
+
+  // ---- single operator: dy / dx fp32 NCHW, dtemb [B][T] (IRB only)
+  void module(const Tens& x1, const float* temb, const float* dy, float* dx, float* dtemb) {
+    const llie_config& g = c->cfg;
+    const Tens& out = tp->hlast;
+    const Tens& x0 = tp->h0;
+    const int T = g.time_embed_dim, F = c->film_rows;
+    const size_t gy = alloc((size_t)B * out.H * out.W * out.C * es());
+    if (!dry) chk(launch_nchw_to_nhwc(dt, dy, p(gy), nullptr, B, out.C, out.H * out.W, out.C, 0, s));
+    gmap[out.off] = gy;
+    const size_t dfilm = g.kind == LLIE_IRB ? alloc((size_t)B * F * 4) : 0;
+    run_ops(dfilm, F);
+    if (g.kind == LLIE_IRB) {
+      const size_t ds = alloc((size_t)B * T * 4);
+      film_bwd(dfilm, F, T, ds);
+      if (!dry) chk(launch_silu_bwd(p<float>(ds), temb, dtemb, (int64_t)B * T, s));
+      ar->free(ds); ar->free(dfilm);
+    }
+    const size_t g0 = take_grad(x0);
+    if (!dry) chk(launch_nhwc_to_nchw(dt, p(g0), dx, B, x0.C, x0.H * x0.W, s, g.in_channels, 0));
+    ar->free(g0);
+    if (x1.valid) {
+      const size_t g1 = take_grad(x1);
+      if (!dry) chk(launch_nhwc_to_nchw(dt, p(g1), dx, B, x1.C, x1.H * x1.W, s, g.in_channels, x0.C));
+      ar->free(g1);
+    }
   }
 };
 
@@ -819,6 +1347,7 @@ void llie_destroy(llie_ctx* c) {
   for (auto& r : c->prof) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
   for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
   if (c->blob) (void)hipFree(c->blob);
+  delete c->train_arena;
   delete c;
 }
 
@@ -849,9 +1378,18 @@ int llie_load_param(llie_ctx* c, const char* key, const float* src, int64_t nume
   hipError_t e = hipSuccess;
   switch (p.kind) {
     case PK_F32: e = hipMemcpyAsync(dst, src, (size_t)numel * 4, hipMemcpyDeviceToDevice, s); break;
-    case PK_MAT: e = launch_cvt_rows(p.as_t ? c->dt : 0, src, dst, p.rows, p.cols, p.ld, p.col0, s); break;
-    case PK_CONV3: e = launch_repack_conv3x3(c->dt, src, dst, p.O, p.I, s); break;
-    case PK_DW: e = launch_repack_dw(src, reinterpret_cast<float*>(dst), p.O, s); break;
+    case PK_MAT:
+      e = launch_cvt_rows(p.as_t ? c->dt : 0, src, dst, p.rows, p.cols, p.ld, p.col0, s);
+      if (e == hipSuccess && p.has_t) e = launch_cvt_rows_t(c->dt, src, c->blob + p.t_off, p.rows, p.cols, s);
+      break;
+    case PK_CONV3:
+      e = launch_repack_conv3x3(c->dt, src, dst, p.O, p.I, s);
+      if (e == hipSuccess && p.has_t) e = launch_repack_conv3x3_t(c->dt, src, c->blob + p.t_off, p.O, p.I, s);
+      break;
+    case PK_DW:
+      e = launch_repack_dw(src, reinterpret_cast<float*>(dst), p.O, s);
+      if (e == hipSuccess && p.has_t) e = launch_repack_dw_flip(src, reinterpret_cast<float*>(c->blob + p.t_off), p.O, s);
+      break;
     case PK_INIT:
       e = launch_repack_init(src, reinterpret_cast<float*>(dst), p.O, p.I, s);
       if (e == hipSuccess && c->dt != LLIE_F32) e = launch_repack_init_mfma(c->dt, src, c->blob + c->init_wp, p.O, p.I, s);
@@ -944,6 +1482,94 @@ int llie_module_forward(llie_ctx* c, const float* x, const float* temb, float* y
   Run r{c, &ar, reinterpret_cast<hipStream_t>(stream), reinterpret_cast<char*>(ws), false, batch, c->dt};
   r.module(x, temb, y, H, W);
   return finish_run(r, ws_bytes);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Training: forward that keeps its activations + reverse pass over the tape.
+int64_t llie_grad_numel(const llie_ctx* c) { return c ? c->grad_numel : LLIE_ERR_ARG; }
+int64_t llie_param_grad_offset(const llie_ctx* c, int i) {
+  if (!c || i < 0 || i >= (int)c->params.size()) return LLIE_ERR_ARG;
+  return c->params[i].goff;
+}
+
+int64_t llie_train_workspace_bytes(llie_ctx* c, int batch, int height, int width) {
+  if (!c || batch <= 0) return LLIE_ERR_ARG;
+  Arena ar((size_t)1 << 46);
+  Tape tape;
+  Run r{c, &ar, nullptr, nullptr, true, batch, c->dt};
+  r.tape = &tape;
+  Back b{c, &ar, nullptr, nullptr, true, batch, c->dt, &tape, nullptr};
+  if (c->cfg.kind == LLIE_UNET) {
+    r.unet(nullptr, nullptr, nullptr, 0, nullptr);
+    b.unet(nullptr);
+  } else {
+    if (shape_ok(c, height, width) != LLIE_OK) return LLIE_ERR_SHAPE;
+    r.module(nullptr, nullptr, nullptr, height, width);
+    b.module(r.mod_x1, nullptr, nullptr, nullptr, nullptr);
+  }
+  if (b.err != hipSuccess) { set_err("training plan is inconsistent"); return LLIE_ERR_ARG; }
+  return (int64_t)ar.high;
+}
+
+int llie_unet_train_forward(llie_ctx* c, const float* lat, const float* cond, const int64_t* t, float* eps, int batch,
+                            void* ws, int64_t ws_bytes, llie_stream stream) {
+  if (!c || !lat || !cond || !t || !eps || !ws || batch <= 0 || c->cfg.kind != LLIE_UNET) return LLIE_ERR_ARG;
+  if (!c->blob) { set_err("no HIP device"); return LLIE_ERR_NO_DEVICE; }
+  int rc = check_loaded(c);
+  if (rc) return rc;
+  const int64_t need = llie_train_workspace_bytes(c, batch, 0, 0);
+  if (need < 0) return (int)need;
+  if (need > ws_bytes) { set_err("workspace too small: need %lld, have %lld", (long long)need, (long long)ws_bytes); return LLIE_ERR_WORKSPACE; }
+  delete c->train_arena;
+  c->train_arena = new Arena((size_t)ws_bytes);
+  c->tape.clear();
+  Run r{c, c->train_arena, reinterpret_cast<hipStream_t>(stream), reinterpret_cast<char*>(ws), false, batch, c->dt};
+  r.tape = &c->tape;
+  r.unet(lat, cond, t, 0, eps, nullptr);
+  rc = finish_run(r, ws_bytes);
+  if (rc) return rc;
+  c->tape.valid = true;
+  c->tape.ws = ws;
+  return LLIE_OK;
+}
+
+int llie_unet_backward(llie_ctx* c, const float* d_eps, float* grads, int batch, void* ws, int64_t ws_bytes, llie_stream stream) {
+  if (!c || !d_eps || !grads || !ws || c->cfg.kind != LLIE_UNET) return LLIE_ERR_ARG;
+  if (!c->tape.valid || c->tape.ws != ws || c->tape.B != batch || !c->train_arena || (int64_t)c->train_arena->cap != ws_bytes) {
+    set_err("llie_unet_backward needs the workspace of the preceding llie_unet_train_forward (same batch)");
+    return LLIE_ERR_ARG;
+  }
+  Back b{c, c->train_arena, reinterpret_cast<hipStream_t>(stream), reinterpret_cast<char*>(ws), false, batch, c->dt, &c->tape, grads};
+  b.unet(d_eps);
+  if (c->train_arena->failed) { set_err("workspace too small for the backward pass"); return LLIE_ERR_WORKSPACE; }
+  if (b.err != hipSuccess) { set_err("HIP error %d: %s", (int)b.err, hipGetErrorString(b.err)); return (int)b.err; }
+  return LLIE_OK;
+}
+
+int llie_module_backward(llie_ctx* c, const float* x, const float* temb, const float* dy, float* dx, float* dtemb, float* grads,
+                         int batch, int H, int W, void* ws, int64_t ws_bytes, llie_stream stream) {
+  if (!c || !x || !dy || !dx || !grads || !ws || batch <= 0 || c->cfg.kind == LLIE_UNET) return LLIE_ERR_ARG;
+  if (c->cfg.kind == LLIE_IRB && (!temb || !dtemb)) return LLIE_ERR_ARG;
+  if (!c->blob) { set_err("no HIP device"); return LLIE_ERR_NO_DEVICE; }
+  int rc = check_loaded(c);
+  if (rc) return rc;
+  rc = shape_ok(c, H, W);
+  if (rc) return rc;
+  const int64_t need = llie_train_workspace_bytes(c, batch, H, W);
+  if (need < 0) return (int)need;
+  if (need > ws_bytes) { set_err("workspace too small: need %lld, have %lld", (long long)need, (long long)ws_bytes); return LLIE_ERR_WORKSPACE; }
+  Arena ar((size_t)ws_bytes);
+  Tape tape;
+  Run r{c, &ar, reinterpret_cast<hipStream_t>(stream), reinterpret_cast<char*>(ws), false, batch, c->dt};
+  r.tape = &tape;
+  r.module(x, temb, nullptr, H, W);
+  rc = finish_run(r, ws_bytes);
+  if (rc) return rc;
+  Back b{c, &ar, reinterpret_cast<hipStream_t>(stream), reinterpret_cast<char*>(ws), false, batch, c->dt, &tape, grads};
+  b.module(r.mod_x1, temb, dy, dx, dtemb);
+  if (ar.failed) { set_err("workspace too small for the backward pass"); return LLIE_ERR_WORKSPACE; }
+  if (b.err != hipSuccess) { set_err("HIP error %d: %s", (int)b.err, hipGetErrorString(b.err)); return (int)b.err; }
+  return LLIE_OK;
 }
 
 int llie_lcm_step(const float* mo, const float* sample, const float* noise, float* prev, float* x0, float* clamped,

@@ -73,6 +73,8 @@ struct GnFinalizeArgs {
   float* as;         // [B][C]
   float* ab;         // [B][C]
   int B;
+  float* mean_out;   // optional [B][groups] (training: kept for the backward pass)
+  float* rstd_out;
 };
 hipError_t launch_gn_finalize(const GnFinalizeArgs& a, hipStream_t s);
 
@@ -84,6 +86,7 @@ struct DwArgs {
   const float* w;
   float* pool;
   int B, H, W, C;
+  int no_act;        // 1: prologue is the affine alone (backward: dh2 = da3*gate + dmean/P), 0: affine + ReLU6
 };
 hipError_t launch_dwconv3x3(int dtype, const DwArgs& a, hipStream_t s);
 
@@ -167,7 +170,8 @@ struct FinalConvArgs {
   const float* sample; const float* noise; float* prev; float* clamped;
 };
 hipError_t launch_final_conv(int dtype, const FinalConvArgs& a, hipStream_t s);
-//   implicit-GEMM MFMA conv: mode 0 = stride-2 downsample, 1 = bilinear x2 upsample then conv (pad 1).
+//   implicit-GEMM MFMA conv: mode 0 = stride-2 downsample, 1 = bilinear x2 upsample then conv (pad 1),
+//   2 = plain stride-1 conv (training: conv on the stored upsampled tensor, and every input-gradient conv).
 struct Conv3Args {
   const void* in;      // NHWC [B][Hi][Wi][C]
   const void* w;       // [9][Cout][Cin] T
@@ -204,13 +208,15 @@ constexpr int kAffineTileRows = 64;
 //   x is [B][Csrc][P]; channels [coff, coff+C) are converted.
 hipError_t launch_nchw_to_nhwc(int dtype, const float* x, void* y, float* stats, int B, int C, int P, int Csrc,
                                int coff, hipStream_t s);
-hipError_t launch_nhwc_to_nchw(int dtype, const void* x, float* y, int B, int C, int P, hipStream_t s);
+hipError_t launch_nhwc_to_nchw(int dtype, const void* x, float* y, int B, int C, int P, hipStream_t s, int Cdst = 0,
+                               int coff = 0);  // y is [B][Cdst][P]; the C channels land at [coff, coff+C)
 
 // Weight repack at load time (fp32 reference layout -> engine layout).
 hipError_t launch_cvt_rows(int dtype, const float* src, void* dst, int rows, int cols, int dst_ld, int dst_col0,
                            hipStream_t s);                       // dst[r*ld + col0 + c] = T(src[r*cols + c])
 hipError_t launch_repack_conv3x3(int dtype, const float* src, void* dst, int Cout, int Cin, hipStream_t s);  // OIHW -> [9][O][I]
 hipError_t launch_repack_dw(const float* src, float* dst, int C, hipStream_t s);                             // [C][1][3][3] -> [9][C]
+hipError_t launch_repack_dw_flip(const float* src, float* dst, int C, hipStream_t s);                        // [C][1][3][3] -> [8-tap][C]
 hipError_t launch_repack_init(const float* src, float* dst, int O, int I, hipStream_t s);                    // OIHW -> [I*9][O]
 hipError_t launch_repack_final(const float* src, float* dst, int O, int I, hipStream_t s);                   // OIHW -> [9][I][4]
 hipError_t launch_repack_final_mfma(int dtype, const float* src, void* dst, int O, int I, hipStream_t s);    // OIHW -> [I/32][18][2][4][8] T
@@ -225,5 +231,137 @@ hipError_t launch_lcm_step(const float* eps, const float* x, const float* noise,
                            float* clamped, int64_t n, StepCoef c, hipStream_t s);
 hipError_t launch_add_noise(const float* x0, const float* noise, const int64_t* t, const float* acp, float* out,
                             int B, int64_t per, int velocity, hipStream_t s);
+
+
+// =============================================================================================
+// Training: backward kernels (bwd.hip, wgrad.hip).  Gradients of activations are NHWC T like the
+// activations; parameter gradients are fp32 in the reference's state_dict layout.  Every reduction
+// runs in a fixed order (tile partials, then a sequential combine), so gradients are reproducible.
+
+// (1) activation backward + per-channel partial sums for the GroupNorm backward:
+//   dz = g * act'(x*as + ab)   (ReLU6 / SiLU / none);   slab[b][tile][0][c] = sum dz, [1] = sum dz * x  (tiles of 64 rows)
+// x is the (virtually concatenated) input of the norm.  dz may alias g; null = do not store (act none).
+struct BwdMaskArgs {
+  const void* g;
+  const void* x0; const void* x1; int c0, c1;
+  const float* as; const float* ab;
+  int act;
+  void* dz;
+  float* slab;
+  int M, C, P;
+};
+hipError_t launch_bwd_mask_reduce(int dtype, const BwdMaskArgs& a, hipStream_t s);
+
+// sum a slab over its tiles: out[b][j][c] = sum_t slab[b][t][j][c] for j < nj_out (slab rows have nj entries; pre-offset
+// the pointer by j0*C to pick a single component).  Fixed order.
+hipError_t launch_slab_reduce(const float* slab, float* out, int B, int ntiles, int nj, int nj_out, int C, hipStream_t s);
+// out[c] = sum_b in[b*stride + c]
+hipError_t launch_batch_sum(const float* in, float* out, int B, int64_t stride, int C, hipStream_t s);
+
+// (2) GroupNorm backward coefficients from the reduced sums S[b][2][C] and the forward mean / rstd:
+//   dx = dz*A + x*Bq + Cq;  dG[b][c] = sum dz*xhat,  dBc[b][c] = sum dz  (before the FiLM / batch reductions)
+struct GnBwdArgs {
+  const float* S; const float* mean; const float* rstd;   // [B][2][C], [B][groups], [B][groups]
+  const float* gamma; const float* film; int64_t film_stride;  // FiLM rows of the forward (scale at c, shift at C+c) or null
+  int C, groups, P, B;
+  float* A; float* Bq; float* Cq; float* dG; float* dBc;   // [B][C] each
+};
+hipError_t launch_gn_bwd_coef(const GnBwdArgs& a, hipStream_t s);
+//   parameter gradients: dgamma[c] = sum_b dG*(1+s), dbeta[c] = sum_b dBc*(1+s);  FiLM: ds = dG*gamma + dBc*beta, df = dBc
+struct GnParamGradArgs {
+  const float* dG; const float* dBc; const float* gamma; const float* beta;
+  const float* film; int64_t film_stride;
+  float* dgamma; float* dbeta;
+  float* dfilm; int64_t dfilm_stride;   // row b: [c] <- ds, [C + c] <- df  (pre-offset to this block's rows) or null
+  int B, C;
+};
+hipError_t launch_gn_param_grad(const GnParamGradArgs& a, hipStream_t s);
+// (3) dx = dz*A + x*Bq + Cq (+ add0) (+ add1): x / dx / add1 follow the virtual-concat split, add0 is dense [M][C]
+struct GnApplyArgs {
+  const void* dz; const void* x0; const void* x1; int c0, c1;
+  const float* A; const float* Bq; const float* Cq;
+  const void* add0; const void* add1_0; const void* add1_1;
+  void* dx0; void* dx1;
+  int M, P;
+};
+hipError_t launch_gn_bwd_apply(int dtype, const GnApplyArgs& a, hipStream_t s);
+hipError_t launch_add_into(int dtype, void* dst, const void* src, int64_t n, hipStream_t s);   // dst += src
+hipError_t launch_fill_zero(void* dst, int64_t bytes, hipStream_t s);
+
+// (4) weight gradient of a 1x1 / one tap of a 3x3 convolution (TN GEMM on MFMA, split over the rows):
+//   out[n*ldn + k*ldk + off] = sum_m g[m][n] * A'[src(m)][k],   A' = act(a*as + ab) per K-segment as in GemmArgs;
+//   src(m) = pixel (y*stride + dy, x*stride + dx) of the input image (zero outside), m = (b, y, x) over Ho x Wo.
+struct WgradArgs {
+  const void* g; int N;
+  GemmSeg seg[3]; int nseg; int K;
+  int B, Ho, Wo, Hi, Wi, stride, dy, dx;
+  float* partial;      // [msplit][N][K] scratch
+  float* out; int64_t ldn, ldk, off;
+  int msplit;
+};
+int wgrad_msplit(int M, int N, int K);
+hipError_t launch_wgrad(int dtype, const WgradArgs& a, hipStream_t s);
+
+// (5) depthwise 3x3 weight gradient: dw[c][tap] (reference layout [C][1][3][3]) =
+//   sum_{b,y,x} (g*gs[b][c] + gb[b][c]) * relu6(h*as[b][c] + ab[b][c]) at (y+ky-1, x+kx-1)
+struct DwWgradArgs {
+  const void* g; const float* gs; const float* gb;     // incoming gradient and its affine
+  const void* h; const float* as; const float* ab;     // forward input of the depthwise conv and its affine (+ReLU6)
+  float* partial;      // [B*strips][9][C] scratch
+  float* out;          // [C][9]
+  int B, H, W, C;
+};
+int dw_wgrad_strips(int H, int W);
+hipError_t launch_dw_wgrad(int dtype, const DwWgradArgs& a, hipStream_t s);
+
+// (6) small dense pieces over the batch (SE MLP, FiLM / time-embedding Linears): fp32 activations
+//   linear_dx:  dx[b][k] (=|+=) sum_r dy[b][r] * W[r][k]      (W is [R][Kc], T or fp32)
+//   linear_dw:  dW[r][k] = sum_b dy[b][r] * x[b][k],  db[r] = sum_b dy[b][r]      (fp32 outputs)
+//   dy rows have stride dy_stride (>= R) so that a slice of a wider table can be used in place
+hipError_t launch_linear_dx(int wdtype, const float* dy, int64_t dy_stride, const void* W, float* dx, int B, int R, int Kc,
+                            hipStream_t s);
+hipError_t launch_linear_dw(const float* dy, int64_t dy_stride, const float* x, float* dW, float* db, int B, int R, int Kc,
+                            hipStream_t s);
+//   SE gate: dpre2 = dgate * g*(1-g);  ReLU6 hidden: dpre1 = dr * [0 < r < 6];  SiLU: dx = dy * silu'(x)
+hipError_t launch_sigmoid_bwd(const float* dgate, const float* gate, float* out, int64_t n, hipStream_t s);
+hipError_t launch_relu6_bwd(const float* dy, const float* y, float* out, int64_t n, hipStream_t s);
+hipError_t launch_silu_bwd(const float* dy, const float* x, float* out, int64_t n, hipStream_t s);
+hipError_t launch_scale_rows(const float* x, float* out, int64_t n, float scale, hipStream_t s);
+//   sinusoidal embedding rows (SinusoidalPosEmb, efficient_unet.py:68-76) for the time-MLP weight gradient
+hipError_t launch_sin_embed(const int64_t* t, const float* freqs, float* emb, int rows, int dim, hipStream_t s);
+
+// (7) dense 3x3 pieces
+hipError_t launch_upsample2x(int dtype, const void* in, void* out, int B, int Hi, int Wi, int C, hipStream_t s);       // bilinear, align_corners=False
+hipError_t launch_upsample2x_bwd(int dtype, const void* dout, void* din, int B, int Hi, int Wi, int C, hipStream_t s); // adjoint
+hipError_t launch_dilate2x(int dtype, const void* in, void* out, int B, int Hi, int Wi, int C, hipStream_t s);          // out[2y][2x] = in[y][x], zeros elsewhere
+hipError_t launch_repack_conv3x3_t(int dtype, const float* src, void* dst, int Cout, int Cin, hipStream_t s);           // OIHW -> [8-tap][I][O] (input-gradient conv)
+hipError_t launch_cvt_rows_t(int dtype, const float* src, void* dst, int rows, int cols, hipStream_t s);                // dst[c][r] = T(src[r][c])
+//   output head: d(eps) fp32 NCHW [B][Cout][H][W] -> da NHWC [M][C] T (gradient of the SiLU output), and its weight gradient
+struct FinalBwdArgs {
+  const float* deps; const float* w;       // w: the forward kernel's repacked fp32 weights [9][C][4]
+  const void* h; const float* as; const float* ab;   // forward input of the final norm and its affine (SiLU follows)
+  void* da;                                 // [M][C] T
+  float* partial; float* dw; float* dbias;  // partial: [B*H/8][Cout*9][C]; dw OIHW; dbias [Cout]
+  int B, H, W, C, Cout;
+};
+hipError_t launch_final_bwd_data(int dtype, const FinalBwdArgs& a, hipStream_t s);
+hipError_t launch_final_bwd_weight(int dtype, const FinalBwdArgs& a, hipStream_t s);
+//   input conv: weight gradient from d(h0) NHWC [M][Cout] T and the fp32 NCHW input planes
+struct InitBwdArgs {
+  const void* g; const float* x0; const float* x1; int c0, c1;
+  float* partial; float* dw; float* dbias;  // partial [B*H/8][Cin*9 + 1][Cout]; dw OIHW [Cout][Cin][3][3]
+  int B, H, W, Cout;
+};
+hipError_t launch_init_bwd_weight(int dtype, const InitBwdArgs& a, hipStream_t s);
+
+// (8) linear attention backward.  qkv / dqkv NHWC [B][N][3*inner]; kv = forward partials [nsplit][B][heads][32][33].
+struct AttnBwdArgs {
+  const void* qkv; const void* dout; void* dqkv;
+  const float* kv; int nsplit;
+  float* dkv;          // [B][heads][N/64][32][33] partials written by pass A, read by pass B
+  int B, N, heads;
+};
+hipError_t launch_linattn_bwd_q(int dtype, const AttnBwdArgs& a, hipStream_t s);
+hipError_t launch_linattn_bwd_kv(int dtype, const AttnBwdArgs& a, hipStream_t s);
 
 }  // namespace llie

@@ -66,6 +66,10 @@ __global__ void __launch_bounds__(256) gn_finalize_kernel(const GnFinalizeArgs a
   if (var < 0.0) var = 0.0;
   const float rstd = (float)(1.0 / sqrt(var + (double)a.eps));
   const float fmean = (float)mean;
+  if (a.mean_out && tid == 0) {
+    a.mean_out[(size_t)b * a.groups + g] = fmean;
+    a.rstd_out[(size_t)b * a.groups + g] = rstd;
+  }
   for (int i = tid; i < cg; i += 256) {
     const int c = c_lo + i;
     const float ga = a.gamma[c] * rstd;
@@ -514,7 +518,7 @@ __global__ void __launch_bounds__(256) nchw_to_nhwc_kernel(const float* x, T* y,
   }
 }
 template <typename T>
-__global__ void __launch_bounds__(256) nhwc_to_nchw_kernel(const T* x, float* y, int C, int P) {
+__global__ void __launch_bounds__(256) nhwc_to_nchw_kernel(const T* x, float* y, int C, int P, int Cdst, int coff) {
   __shared__ float sm[32 * 65];
   const int tid = threadIdx.x;
   const int b = blockIdx.y, p0 = blockIdx.x * 64, c0 = blockIdx.z * 32;
@@ -525,7 +529,7 @@ __global__ void __launch_bounds__(256) nhwc_to_nchw_kernel(const T* x, float* y,
   __syncthreads();
   for (int i = tid; i < 32 * 64; i += 256) {
     const int c = i >> 6, p = i & 63;
-    y[((size_t)b * C + c0 + c) * P + p0 + p] = sm[c * 65 + p];
+    y[((size_t)b * Cdst + coff + c0 + c) * P + p0 + p] = sm[c * 65 + p];
   }
 }
 hipError_t launch_nchw_to_nhwc(int dtype, const float* x, void* y, float* stats, int B, int C, int P, int Csrc, int coff,
@@ -540,13 +544,14 @@ hipError_t launch_nchw_to_nhwc(int dtype, const float* x, void* y, float* stats,
   }
   return hipGetLastError();
 }
-hipError_t launch_nhwc_to_nchw(int dtype, const void* x, float* y, int B, int C, int P, hipStream_t s) {
+hipError_t launch_nhwc_to_nchw(int dtype, const void* x, float* y, int B, int C, int P, hipStream_t s, int Cdst, int coff) {
+  if (Cdst <= 0) Cdst = C;
   if (P % 64 || C % 32) return hipErrorInvalidValue;
   dim3 grid(P / 64, B, C / 32);
   switch (dtype) {
-    case 0: hipLaunchKernelGGL(nhwc_to_nchw_kernel<float>, grid, dim3(256), 0, s, (const float*)x, y, C, P); break;
-    case 1: hipLaunchKernelGGL(nhwc_to_nchw_kernel<half_t>, grid, dim3(256), 0, s, (const half_t*)x, y, C, P); break;
-    case 2: hipLaunchKernelGGL(nhwc_to_nchw_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)x, y, C, P); break;
+    case 0: hipLaunchKernelGGL(nhwc_to_nchw_kernel<float>, grid, dim3(256), 0, s, (const float*)x, y, C, P, Cdst, coff); break;
+    case 1: hipLaunchKernelGGL(nhwc_to_nchw_kernel<half_t>, grid, dim3(256), 0, s, (const half_t*)x, y, C, P, Cdst, coff); break;
+    case 2: hipLaunchKernelGGL(nhwc_to_nchw_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)x, y, C, P, Cdst, coff); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();
@@ -600,6 +605,17 @@ __global__ void repack_dw_kernel(const float* src, float* dst, int C) {
 }
 hipError_t launch_repack_dw(const float* src, float* dst, int C, hipStream_t s) {
   hipLaunchKernelGGL(repack_dw_kernel, dim3((C * 9 + 255) / 256), dim3(256), 0, s, src, dst, C);
+  return hipGetLastError();
+}
+// taps flipped: the input-gradient of a depthwise conv is the same conv with w'[t] = w[8 - t]
+__global__ void repack_dw_flip_kernel(const float* src, float* dst, int C) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= C * 9) return;
+  const int tap = i % 9, c = i / 9;
+  dst[(8 - tap) * C + c] = src[i];
+}
+hipError_t launch_repack_dw_flip(const float* src, float* dst, int C, hipStream_t s) {
+  hipLaunchKernelGGL(repack_dw_flip_kernel, dim3((C * 9 + 255) / 256), dim3(256), 0, s, src, dst, C);
   return hipGetLastError();
 }
 

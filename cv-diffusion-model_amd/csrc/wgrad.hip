@@ -1,0 +1,162 @@
+// Weight gradient of the pointwise (1x1) convolutions and, one tap per launch, of the dense 3x3
+// convolutions: a TN GEMM  dW[n][k] = sum_m g[m][n] * A'[src(m)][k]  on MFMA.
+//
+// The contraction runs over pixels, which is the slow index of both NHWC operands, so each 64-row
+// chunk is transposed on its way into LDS ([channel][row]); a lane then reads 16 contiguous rows of
+// its channel per 32-row MFMA chunk (the same operand scheme as the forward GEMM, with the roles of
+// rows and channels swapped).  The rows are split over blockIdx.z; the fp32 partials are summed in
+// split order by a second kernel, so the result does not depend on scheduling.
+#include <string>
+
+#include "common.h"
+
+namespace llie {
+
+constexpr int kWgRows = 64;  // rows (pixels) per staged chunk
+
+template <typename T>
+__global__ void __launch_bounds__(256) wgrad_kernel(const WgradArgs a, int rows_per_split) {
+  constexpr int VEC = Elem<T>::VEC, VPR = 64 / VEC, RPP = 256 / VPR, NP = kWgRows / RPP;  // passes to load 64 rows x 64 channels
+  constexpr int PITCH = kWgRows + Elem<T>::VEC;
+  __shared__ __align__(16) T sG[64 * PITCH];
+  __shared__ __align__(16) T sA[64 * PITCH];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wn = wave >> 1, wk = wave & 1;
+  const int n0 = blockIdx.x * 64, k0 = blockIdx.y * 64;
+  const int cv = (tid % VPR) * VEC, rl = tid / VPR;
+  const int P = a.Ho * a.Wo;
+  const size_t m_begin = (size_t)blockIdx.z * rows_per_split;
+
+  // K segment of this thread's A channels
+  const int kc = k0 + cv;
+  const T* aptr = nullptr;
+  int ach = 0, aoff = 0, aact = ACT_NONE, ald = 0;
+  const float* aas = nullptr;
+  const float* aab = nullptr;
+  if (kc < a.K) {
+    int base = 0;
+    for (int sgi = 0; sgi < a.nseg; ++sgi) {
+      const GemmSeg sg = a.seg[sgi];
+      if (kc < base + sg.ch) {
+        aptr = reinterpret_cast<const T*>(sg.ptr); ach = sg.ch; aoff = kc - base;
+        aas = sg.as; aab = sg.ab; ald = sg.aff_ld; aact = sg.act;
+        break;
+      }
+      base += sg.ch;
+    }
+  }
+  const bool g_ok = n0 + cv < a.N;
+  const T* gp = reinterpret_cast<const T*>(a.g);
+
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  typedef typename Elem<T>::vec_t vec_t;
+  vec_t zero;
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) zero[e] = (T)0.f;
+
+  for (int mc = 0; mc < rows_per_split; mc += kWgRows) {
+    vec_t gv[NP], av[NP];
+#pragma unroll
+    for (int ps = 0; ps < NP; ++ps) {
+      const size_t m = m_begin + mc + ps * RPP + rl;
+      gv[ps] = g_ok ? ld_vec<T>(gp + m * a.N + n0 + cv) : zero;
+      av[ps] = zero;
+      if (aptr) {
+        const int b = (int)(m / P);
+        const int pix = (int)(m % P);
+        const int y = (pix / a.Wo) * a.stride + a.dy, x = (pix % a.Wo) * a.stride + a.dx;
+        if (y >= 0 && y < a.Hi && x >= 0 && x < a.Wi) {
+          vec_t v = ld_vec<T>(aptr + (((size_t)b * a.Hi + y) * a.Wi + x) * ach + aoff);
+          if (aas || aact != ACT_NONE) {
+            float f[VEC];
+            vec_to_f32<T>(v, f);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+              float t = f[e];
+              if (aas) t = t * aas[(size_t)b * ald + aoff + e] + (aab ? aab[(size_t)b * ald + aoff + e] : 0.f);
+              f[e] = apply_act(t, aact);
+            }
+            v = f32_to_vec<T>(f);
+          }
+          av[ps] = v;
+        }
+      }
+    }
+    __syncthreads();  // previous chunk's MFMA reads are done
+#pragma unroll
+    for (int ps = 0; ps < NP; ++ps) {
+      const int r = ps * RPP + rl;
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        sG[(cv + e) * PITCH + r] = gv[ps][e];
+        sA[(cv + e) * PITCH + r] = av[ps][e];
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ch = 0; ch < kWgRows / 32; ++ch) {
+      T fa[16], fb[16];
+      const T* pa = sG + (wn * 32 + (lane & 31)) * PITCH + ch * 32 + (lane >> 5) * 16;
+      const T* pb = sA + (wk * 32 + (lane & 31)) * PITCH + ch * 32 + (lane >> 5) * 16;
+#pragma unroll
+      for (int q = 0; q < 16 / VEC; ++q) {
+        *reinterpret_cast<vec_t*>(&fa[q * VEC]) = *reinterpret_cast<const vec_t*>(pa + q * VEC);
+        *reinterpret_cast<vec_t*>(&fb[q * VEC]) = *reinterpret_cast<const vec_t*>(pb + q * VEC);
+      }
+      Mfma<T>::chunk(fa, fb, acc);
+    }
+  }
+  // D[row = n (A-operand row)][col = k (B-operand row)]
+  float* out = a.partial + (size_t)blockIdx.z * a.N * a.K;
+  const int k = k0 + wk * 32 + (lane & 31);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int n = n0 + wn * 32 + mfma_row(r, lane);
+    if (n < a.N && k < a.K) out[(size_t)n * a.K + k] = acc[r];
+  }
+}
+
+__global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* partial, float* out, int N, int K, int msplit,
+                                                           int64_t ldn, int64_t ldk, int64_t off) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (int64_t)N * K) return;
+  float s = 0.f;
+  for (int sp = 0; sp < msplit; ++sp) s += partial[(size_t)sp * N * K + i];
+  const int n = (int)(i / K), k = (int)(i % K);
+  out[(size_t)n * ldn + (size_t)k * ldk + off] = s;
+}
+
+// number of row splits: enough workgroups to fill the GPU, each split a multiple of 64 rows
+int wgrad_msplit(int M, int N, int K) {
+  const int tiles = ((N + 63) / 64) * ((K + 63) / 64);
+  int ms = 1;
+  while (tiles * ms < 2048 && M % (ms * 2 * kWgRows) == 0 && M / (ms * 2) >= 256) ms *= 2;
+  return ms;
+}
+
+hipError_t launch_wgrad(int dtype, const WgradArgs& a, hipStream_t s) {
+  const int M = a.B * a.Ho * a.Wo;
+  if (a.msplit < 1 || M % (a.msplit * kWgRows) || a.N % 32 || a.K % 32 || a.nseg < 1 || a.nseg > 3) return hipErrorInvalidValue;
+  int k = 0;
+  for (int i = 0; i < a.nseg; ++i) {
+    if (a.seg[i].ch % 32) return hipErrorInvalidValue;
+    k += a.seg[i].ch;
+  }
+  if (k != a.K) return hipErrorInvalidValue;
+  dim3 grid((a.N + 63) / 64, (a.K + 63) / 64, a.msplit);
+  const int rps = M / a.msplit;
+  switch (dtype) {
+    case 0: hipLaunchKernelGGL(wgrad_kernel<float>, grid, dim3(256), 0, s, a, rps); break;
+    case 1: hipLaunchKernelGGL(wgrad_kernel<half_t>, grid, dim3(256), 0, s, a, rps); break;
+    case 2: hipLaunchKernelGGL(wgrad_kernel<bf16_t>, grid, dim3(256), 0, s, a, rps); break;
+    default: return hipErrorInvalidValue;
+  }
+  const int64_t n = (int64_t)a.N * a.K;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a.partial, a.out, a.N, a.K,
+                     a.msplit, a.ldn, a.ldk, a.off);
+  return hipGetLastError();
+}
+
+}  // namespace llie

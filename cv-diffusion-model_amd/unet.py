@@ -85,6 +85,68 @@ def resolve_compute_dtype(explicit: Optional[str]) -> int:
     return N.LLIE_F32
 
 
+def _grad_views(flat: torch.Tensor, handle: "N.Handle", param_list) -> Tuple[torch.Tensor, ...]:
+    """Per-parameter views (state_dict shapes) of the engine's flat fp32 gradient buffer."""
+    offs = handle.grad_offsets()
+    out = []
+    for (key, shape), o in zip(param_list, offs):
+        n = 1
+        for d in shape:
+            n *= d
+        out.append(flat[o:o + n].view(shape))
+    return tuple(out)
+
+
+class _ModuleFn(torch.autograd.Function):
+    """Single operator with autograd: forward = llie_module_forward, backward = llie_module_backward (which
+    re-runs the forward with its activations kept, then the reverse pass)."""
+
+    @staticmethod
+    def forward(ctx, mod, out_shape, x, temb, *params):
+        ctx.mod = mod
+        ctx.has_temb = temb is not None
+        ctx.save_for_backward(x, temb if temb is not None else x.new_empty(0))
+        return mod._run_module_raw(x, temb, out_shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, temb = ctx.saved_tensors
+        dx, dtemb, grads = ctx.mod._run_module_backward(x, temb if ctx.has_temb else None, dy)
+        return (None, None, dx, dtemb) + grads
+
+
+class _UNetFn(torch.autograd.Function):
+    """EfficientUNet.forward with autograd: the forward keeps its activations in a workspace owned by this
+    node, the backward is llie_unet_backward (parameter gradients only -- the network input is data)."""
+
+    @staticmethod
+    def forward(ctx, unet, latents, cond, t, *params):
+        h = unet._handle(resolve_compute_dtype(unet.compute_dtype))
+        dev = latents.device
+        b, s = latents.shape[0], unet.config.image_size
+        nbytes = h.train_workspace_bytes(b)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        out = torch.empty(b, unet.config.out_channels, s, s, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            N.check(N.lib().llie_unet_train_forward(h.h, latents.data_ptr(), cond.data_ptr(), t.data_ptr(), out.data_ptr(), b,
+                                                    ws.data_ptr(), nbytes, torch.cuda.current_stream(dev).cuda_stream),
+                    "EfficientUNet.forward (training)")
+        ctx.unet, ctx.h, ctx.ws, ctx.nbytes, ctx.batch = unet, h, ws, nbytes, b
+        ctx.keep = (latents, cond, t)  # the backward pass reads them again (input conv, time embedding)
+        return out
+
+    @staticmethod
+    def backward(ctx, d_eps):
+        unet, h, dev = ctx.unet, ctx.h, d_eps.device
+        d_eps = d_eps.detach().float().contiguous()
+        flat = torch.empty(h.grad_numel(), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            N.check(N.lib().llie_unet_backward(h.h, d_eps.data_ptr(), flat.data_ptr(), ctx.batch, ctx.ws.data_ptr(), ctx.nbytes,
+                                               torch.cuda.current_stream(dev).cuda_stream), "EfficientUNet.backward")
+        ctx.ws = None
+        return (None, None, None, None) + _grad_views(flat, h, unet._param_list)
+
+
 class _NativeModule(nn.Module):
     """Parameters live in PyTorch; compute lives behind the C ABI."""
 
@@ -148,9 +210,44 @@ class _NativeModule(nn.Module):
             self._workspaces[key] = ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         return ws
 
+    def _wants_grad(self, *tensors) -> bool:
+        if not torch.is_grad_enabled():
+            return False
+        return any(t is not None and t.requires_grad for t in tensors) or any(p.requires_grad for p in self.parameters())
+
     def _run_module(self, x: torch.Tensor, temb: Optional[torch.Tensor], out_shape) -> torch.Tensor:
         if x.dim() != 4:
             raise ValueError("expected a [B, C, H, W] tensor")
+        if self._wants_grad(x, temb):
+            return _ModuleFn.apply(self, out_shape, x, temb, *[p for _, p in self._ordered_params()])
+        return self._run_module_raw(x, temb, out_shape)
+
+    def _ordered_params(self):
+        sd = dict(self.named_parameters())
+        return [(k, sd[k]) for k, _ in self._param_list]
+
+    def _run_module_backward(self, x: torch.Tensor, temb: Optional[torch.Tensor], dy: torch.Tensor):
+        h = self._handle(resolve_compute_dtype(self.compute_dtype))
+        dev = x.device
+        x = x.detach().float().contiguous()
+        dy = dy.detach().float().contiguous()
+        b, _, hh, ww = x.shape
+        nbytes = h.train_workspace_bytes(b, hh, ww)
+        ws = self._workspace(h, nbytes, dev)
+        dx = torch.empty_like(x)
+        flat = torch.empty(h.grad_numel(), dtype=torch.float32, device=dev)
+        tp = dtp = None
+        dtemb = None
+        if temb is not None:
+            temb = temb.detach().float().contiguous()
+            dtemb = torch.empty_like(temb)
+            tp, dtp = temb.data_ptr(), dtemb.data_ptr()
+        with torch.cuda.device(dev):
+            N.check(N.lib().llie_module_backward(h.h, x.data_ptr(), tp, dy.data_ptr(), dx.data_ptr(), dtp, flat.data_ptr(), b, hh, ww,
+                                                 ws.data_ptr(), ws.numel(), torch.cuda.current_stream(dev).cuda_stream), "backward")
+        return dx, dtemb, _grad_views(flat, h, self._param_list)
+
+    def _run_module_raw(self, x: torch.Tensor, temb: Optional[torch.Tensor], out_shape) -> torch.Tensor:
         h = self._handle(resolve_compute_dtype(self.compute_dtype))
         dev = x.device
         x = x.detach().float().contiguous()
@@ -273,12 +370,15 @@ class EfficientUNet(_NativeModule):
         if latents.shape[1] + cond.shape[1] != self.config.in_channels or latents.shape[1] != self.config.in_channels // 2:
             raise ValueError("channel split does not match in_channels")
         dev = latents.device
-        h, ws, nbytes = self._prepare(b, dev)
         latents = latents.detach().float().contiguous()
         cond = cond.detach().float().contiguous()
         t = timestep.to(device=dev, dtype=torch.long).contiguous()
         if t.numel() != b:
             raise ValueError("timestep must have one entry per batch row")
+        if self._wants_grad() and not uniform_t and out is None:
+            # training: activations are kept and the result carries a grad_fn (parameter gradients only)
+            return _UNetFn.apply(self, latents, cond, t, *[p for _, p in self._ordered_params()])
+        h, ws, nbytes = self._prepare(b, dev)
         if out is None:
             out = torch.empty(b, self.config.out_channels, s, s, dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):

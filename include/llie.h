@@ -125,6 +125,27 @@ int llie_unet_forward(llie_ctx* ctx, const float* latents, const float* cond, co
 int llie_module_forward(llie_ctx* ctx, const float* x, const float* temb, float* y, int batch, int height,
                         int width, void* workspace, int64_t workspace_bytes, llie_stream stream);
 
+/* ---- Training step (callers: src/training/trainer.py:269-338 via LowLightDiffusion.compute_loss,
+ * low_light_diffusion.py:140-171,250-277).  The forward pass keeps its activations in the workspace; the
+ * backward pass walks them in reverse and writes every parameter's gradient, fp32 in the reference's
+ * state_dict layout, into one flat buffer: parameter i (llie_param_info order) at llie_param_grad_offset(i),
+ * llie_grad_numel() floats in total.  Timesteps are per sample (int64[B]).  All reductions run in a fixed
+ * order, so gradients are bitwise reproducible.
+ *   llie_unet_train_forward:  eps = unet(cat[lat, cond], t), activations retained in `workspace`
+ *   llie_unet_backward:       given d(loss)/d(eps) (fp32 NCHW) -> grads; `workspace` must be the untouched
+ *                             buffer of the preceding train_forward; lat / cond / t must still be alive
+ *   llie_module_backward:     single operator (IRB / ATTN / DOWN / UP handles): forward + backward in one call;
+ *                             dx fp32 NCHW like x, dtemb [B][T] (IRB only) */
+int64_t llie_grad_numel(const llie_ctx* ctx);
+int64_t llie_param_grad_offset(const llie_ctx* ctx, int index);
+int64_t llie_train_workspace_bytes(llie_ctx* ctx, int batch, int height, int width);
+int llie_unet_train_forward(llie_ctx* ctx, const float* latents, const float* cond, const int64_t* timesteps, float* eps,
+                            int batch, void* workspace, int64_t workspace_bytes, llie_stream stream);
+int llie_unet_backward(llie_ctx* ctx, const float* d_eps, float* grads, int batch, void* workspace, int64_t workspace_bytes,
+                       llie_stream stream);
+int llie_module_backward(llie_ctx* ctx, const float* x, const float* temb, const float* dy, float* dx, float* dtemb,
+                         float* grads, int batch, int H, int W, void* workspace, int64_t workspace_bytes, llie_stream stream);
+
 /* LCMScheduler.step (lcm_scheduler.py:176-253), elementwise on fp32 [n]:
  *   x0 = (sample - sqrt_beta_t*model_output)/sqrt_alpha_t      (epsilon)
  *   prev = is_last ? x0 : sqrt_alpha_prev*x0 + sqrt_beta_prev*noise
