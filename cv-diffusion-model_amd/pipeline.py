@@ -61,8 +61,13 @@ class LowLightDiffusion(nn.Module):
     def forward(self, low_light: torch.Tensor, normal_light: Optional[torch.Tensor] = None,
                 timesteps: Optional[torch.Tensor] = None, noise: Optional[torch.Tensor] = None,
                 return_dict: bool = True) -> Union[torch.Tensor, Dict[str, torch.Tensor]]:
-        """With `normal_light`: q-sample -> denoiser, returning {noise_pred, noise, timesteps} (no autograd
-        graph: backward kernels are the next scope row).  Without: `enhance(low_light)`."""
+        """With `normal_light`: q-sample -> denoiser, returning {noise_pred, noise, timesteps}.  When gradients
+        are enabled `noise_pred` carries a grad_fn whose backward is the engine's reverse pass
+        (llie_unet_backward): `loss.backward()` fills `.grad` of every parameter, so the reference trainer's
+        step (trainer.py:269-338: AdamW, GradScaler, clip_grad_norm_, EMA) runs unchanged on top.
+        With a `prediction_type="v_prediction"` scheduler the dict also holds the velocity `target`
+        (lcm_scheduler.py:282-305; the reference never wires it into `compute_loss`).
+        Without `normal_light`: `enhance(low_light)`."""
         if normal_light is None:
             return self.enhance(low_light)
         batch, device = low_light.shape[0], low_light.device
@@ -73,7 +78,10 @@ class LowLightDiffusion(nn.Module):
         noisy = self.scheduler.add_noise(normal_light, noise, timesteps)
         noise_pred = self.unet.forward_split(noisy, low_light, timesteps, uniform_t=False)
         if return_dict:
-            return {"noise_pred": noise_pred, "noise": noise, "timesteps": timesteps}
+            out = {"noise_pred": noise_pred, "noise": noise, "timesteps": timesteps}
+            if getattr(self.scheduler.config, "prediction_type", "epsilon") == "v_prediction":
+                out["target"] = self.scheduler.get_velocity(normal_light, noise, timesteps)
+            return out
         return noise_pred
 
     # ------------------------------------------------------------------ inference loop (:177-248)
@@ -136,7 +144,7 @@ class LowLightDiffusion(nn.Module):
     # ------------------------------------------------------------------ loss (:250-277)
     def compute_loss(self, low_light: torch.Tensor, normal_light: torch.Tensor, loss_type: str = "mse") -> torch.Tensor:
         out = self.forward(low_light, normal_light)
-        pred, noise = out["noise_pred"], out["noise"]
+        pred, noise = out["noise_pred"], out.get("target", out["noise"])  # epsilon target, or velocity for v-prediction
         if loss_type == "mse":
             return F.mse_loss(pred, noise)
         if loss_type == "huber":

@@ -3,9 +3,8 @@ the C ABI (llie_module_backward / llie_unet_train_forward + llie_unet_backward) 
 PyTorch autograd run on the CPU oracle (fp32) with the same weights and inputs.
 
 Tolerance: gradients are compared per tensor relative to that tensor's largest reference entry
-(|g - g_ref|_max <= tol * |g_ref|_max); fp32 engine tol = 2e-3 (the forward bar of 1e-3 on outputs,
-doubled for the longer reverse chain through the GroupNorm statistics), bf16/fp16 are checked by cosine
-similarity.
+(|g - g_ref|_max <= tol * |g_ref|_max); single operators in fp32: tol = 1e-4 (measured <= 1e-6); the whole
+network adds relative-L2 / cosine criteria (see that test); bf16 / fp16 engines are checked by cosine similarity.
 """
 import importlib
 
@@ -52,7 +51,7 @@ def ref_grads(fn, sd, inputs):
     return y.detach(), w, [x.grad for x in inputs], {k: v.grad for k, v in sd.items()}
 
 
-def check_module(mod, name, fn, inputs, dev, tol=2e-3):
+def check_module(mod, name, fn, inputs, dev, tol=1e-4):
     sd = {name + "." + k: v.detach().cpu() for k, v in mod.state_dict().items()}
     y_ref, w, gin_ref, gp_ref = ref_grads(fn, sd, inputs)
     dins = [x.to(dev).requires_grad_(True) for x in inputs]
@@ -100,3 +99,151 @@ def test_down_up_backward(dev, c, hw):
     up = fill(M.Upsample(c), name + ".", dev)
     x = synth_input(name + ".x", (2, c, hw // 2, hw // 2), -2, 2)
     check_module(up, name, lambda sd, x: unet_ref.upsample(sd, name, x), [x], dev)
+
+
+# ------------------------------------------------------------------ whole UNet: d(loss)/d(every parameter)
+def _ref_unet_grads(sd, spec, low, normal, t, noise, loss="mse"):
+    import torch.nn.functional as F
+    from oracle import scheduler_ref as S
+    tab = S.LCMTables.build(rescale_betas_zero_snr=True)
+    sdg = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    noisy = S.add_noise(tab, normal, noise, t)
+    pred = oracle.unet_forward(sdg, spec, torch.cat([noisy, low], 1), t)
+    lv = {"mse": F.mse_loss, "l1": F.l1_loss, "huber": F.huber_loss}[loss](pred, noise)
+    lv.backward()
+    return lv.detach(), pred.detach(), {k: v.grad for k, v in sdg.items()}
+
+
+def _small(size, dev):
+    spec = oracle.make_spec("small", size)
+    sd = oracle.synth_state_dict(oracle.param_shapes(spec))
+    m = M.LowLightDiffusion(unet_variant="small", image_size=size, num_inference_steps=4)
+    m.load_state_dict(sd)
+    return m.to(dev).train(), sd, spec
+
+
+@pytest.mark.parametrize("cd,max_l2,min_cos", [(None, 5e-3, 0.9999), ("bf16", 0.25, 0.98), ("fp16", 0.25, 0.98)])
+def test_unet_backward_small64(dev, cd, max_l2, min_cos):
+    """small@64 (11 attention modules, all four levels), B=2, per-sample timesteps: loss, prediction and the
+    gradient of every one of the 381 parameters against CPU autograd (fp32 oracle).
+
+    fp32 engine: measured relative L2 <= 1.9e-3, cosine >= 0.999998, median max-error 8e-5 of the tensor's
+    largest entry; the handful of tensors near 1e-3..1e-2 sit behind 8x8 maps where single ReLU6 mask flips
+    (z within rounding of 0 or 6) move whole gradient entries.  bf16 / fp16 engines: cosine >= 0.99 measured."""
+    m, sd, spec = _small(64, dev)
+    m.compute_dtype = cd
+    try:
+        g = torch.Generator().manual_seed(3)
+        low = torch.rand(2, 3, 64, 64, generator=g) * 2 - 1
+        normal = torch.rand(2, 3, 64, 64, generator=g) * 2 - 1
+        noise = torch.randn(2, 3, 64, 64, generator=g)
+        t = torch.tensor([500, 37])
+        loss_ref, pred_ref, gref = _ref_unet_grads(sd, spec, low, normal, t, noise)
+        m.zero_grad(set_to_none=True)
+        out = m(low.to(dev), normal.to(dev), timesteps=t.to(dev), noise=noise.to(dev))
+        assert out["noise_pred"].grad_fn is not None
+        loss = torch.nn.functional.mse_loss(out["noise_pred"], out["noise"])
+        loss.backward()
+        if cd is None:
+            assert abs(loss.item() - loss_ref.item()) < 1e-5 * max(1.0, abs(loss_ref.item()))
+            assert (out["noise_pred"].detach().cpu() - pred_ref).abs().max() < 1e-3
+        bad, relmax = {}, []
+        for k, p in m.named_parameters():
+            assert p.grad is not None and torch.isfinite(p.grad).all(), k
+            a, b = p.grad.double().cpu(), gref[k].double()
+            l2, cs = ((a - b).norm() / b.norm()).item(), cosine(a, b)
+            relmax.append(rel_err(a, b))
+            if not (l2 < max_l2 and cs > min_cos):
+                bad[k] = (l2, cs)
+        assert not bad, f"{len(bad)} tensors off: {dict(list(bad.items())[:8])}"
+        if cd is None:
+            assert sorted(relmax)[len(relmax) // 2] < 1e-3
+        # the same call again gives the same bits (fixed-order reductions everywhere)
+        g1 = {k: p.grad.clone() for k, p in m.named_parameters()}
+        m.zero_grad(set_to_none=True)
+        out = m(low.to(dev), normal.to(dev), timesteps=t.to(dev), noise=noise.to(dev))
+        torch.nn.functional.mse_loss(out["noise_pred"], out["noise"]).backward()
+        assert all(torch.equal(g1[k], p.grad) for k, p in m.named_parameters())
+    finally:
+        m.compute_dtype = None
+
+
+def test_trainer_step_semantics(dev):
+    """The reference trainer's step (trainer.py:281-338) on top of the engine: compute_loss -> backward ->
+    clip_grad_norm_(1.0) -> AdamW -> EMA, three steps on fixed batches; the loss sequence follows the same
+    steps taken with CPU autograd on the oracle (fp32).  Also the AMP route: autocast(bf16) + GradScaler."""
+    import torch.nn.functional as F
+    from oracle import scheduler_ref as S
+    m, sd, spec = _small(64, dev)
+    m.load_state_dict(sd)
+    g = torch.Generator().manual_seed(11)
+    batches = [(torch.rand(2, 3, 64, 64, generator=g) * 2 - 1, torch.rand(2, 3, 64, 64, generator=g) * 2 - 1,
+                torch.randn(2, 3, 64, 64, generator=g), torch.randint(0, 1000, (2,), generator=g)) for _ in range(3)]
+    # CPU reference: same optimiser on the oracle's parameters
+    ref_p = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    opt_r = torch.optim.AdamW(list(ref_p.values()), lr=1e-4, weight_decay=0.01)
+    tab = S.LCMTables.build(rescale_betas_zero_snr=True)
+    ref_losses = []
+    for low, normal, noise, t in batches:
+        opt_r.zero_grad()
+        pred = oracle.unet_forward(ref_p, spec, torch.cat([S.add_noise(tab, normal, noise, t), low], 1), t)
+        loss = F.mse_loss(pred, noise)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(list(ref_p.values()), 1.0)
+        opt_r.step()
+        ref_losses.append(loss.item())
+    opt = torch.optim.AdamW(m.parameters(), lr=1e-4, weight_decay=0.01)
+    ema = {k: p.detach().clone() for k, p in m.named_parameters()}
+    losses = []
+    for low, normal, noise, t in batches:
+        opt.zero_grad()
+        out = m(low.to(dev), normal.to(dev), timesteps=t.to(dev), noise=noise.to(dev))
+        loss = F.mse_loss(out["noise_pred"], out["noise"])
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(m.parameters(), 1.0)
+        opt.step()
+        for k, p in m.named_parameters():
+            ema[k].mul_(0.9999).add_(p.detach(), alpha=1 - 0.9999)
+        losses.append(loss.item())
+    for a, b in zip(losses, ref_losses):
+        assert abs(a - b) < 2e-3 * max(1.0, abs(b)), (losses, ref_losses)
+    # parameters moved the same way: AdamW's first steps are sign-like, so compare the update direction
+    moved = 0
+    for k, p in m.named_parameters():
+        d_gpu, d_ref = (p.detach().cpu() - sd[k]).flatten(), (ref_p[k].detach() - sd[k]).flatten()
+        if d_ref.norm() > 0:
+            assert cosine(d_gpu, d_ref) > 0.9, k
+            moved += 1
+    assert moved == len(sd)
+    # AMP route of the reference trainer (autocast + GradScaler): runs, scales, steps
+    m.load_state_dict(sd)
+    opt = torch.optim.AdamW(m.parameters(), lr=1e-4)
+    scaler = torch.amp.GradScaler("cuda", init_scale=1024.0)
+    low, normal, noise, t = batches[0]
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        loss = m.compute_loss(low.to(dev), normal.to(dev))
+    scaler.scale(loss).backward()
+    scaler.unscale_(opt)
+    gn = torch.nn.utils.clip_grad_norm_(m.parameters(), 1.0)
+    scaler.step(opt)
+    scaler.update()
+    assert torch.isfinite(gn) and torch.isfinite(loss)
+
+
+def test_v_prediction_target_and_loss_types(dev):
+    """compute_loss wiring: epsilon target by default, velocity target with a v_prediction scheduler
+    (lcm_scheduler.py:282-305), the three loss types, ValueError otherwise (low_light_diffusion.py:274-275)."""
+    m, sd, spec = _small(64, dev)
+    low = (torch.rand(2, 3, 64, 64) * 2 - 1).to(dev)
+    normal = (torch.rand(2, 3, 64, 64) * 2 - 1).to(dev)
+    for lt in ("mse", "huber", "l1"):
+        loss = m.compute_loss(low, normal, loss_type=lt)
+        assert loss.grad_fn is not None and torch.isfinite(loss)
+    with pytest.raises(ValueError):
+        m.compute_loss(low, normal, loss_type="nope")
+    mv = M.LowLightDiffusion(unet=m.unet, image_size=64, scheduler=M.LCMScheduler(prediction_type="v_prediction",
+                                                                                  rescale_betas_zero_snr=True))
+    t = torch.tensor([100, 900], device=dev)
+    noise = torch.randn(2, 3, 64, 64, device=dev)
+    out = mv(low, normal, timesteps=t, noise=noise)
+    assert torch.equal(out["target"], mv.scheduler.get_velocity(normal, noise, t))
