@@ -374,30 +374,48 @@ hipError_t launch_dw_wgrad(int dtype, const DwWgradArgs& a, hipStream_t s) {
 
 // =============================================================================================
 // (6) small dense pieces over the batch
+// dx[b][k] = sum_r dy[b][r] * W[r][k].  R is cut into gridDim.z chunks (long FiLM tables would otherwise run on a
+// handful of CUs); each chunk writes its partial row, a second kernel adds the chunks in order.
 template <typename WT>
-__global__ void __launch_bounds__(256) linear_dx_kernel(const float* dy, int64_t dy_stride, const WT* W, float* dx, int R, int Kc) {
+__global__ void __launch_bounds__(256) linear_dx_kernel(const float* dy, int64_t dy_stride, const WT* W, float* dst, int R, int Kc,
+                                                        int rchunk, int B) {
   __shared__ float part[4][64];
   const int tid = threadIdx.x, kl = tid & 63, rg = tid >> 6;
   const int k = blockIdx.x * 64 + kl, b = blockIdx.y;
+  const int r0 = blockIdx.z * rchunk, r1 = min(r0 + rchunk, R);
   float acc = 0.f;
   if (k < Kc) {
     const float* dyr = dy + (size_t)b * dy_stride;
-    for (int r = rg; r < R; r += 4) acc += dyr[r] * (float)W[(size_t)r * Kc + k];
+    for (int r = r0 + rg; r < r1; r += 4) acc += dyr[r] * (float)W[(size_t)r * Kc + k];
   }
   part[rg][kl] = acc;
   __syncthreads();
-  if (rg == 0 && k < Kc) {
-    dx[(size_t)b * Kc + k] = (part[0][kl] + part[1][kl]) + (part[2][kl] + part[3][kl]);
-  }
+  if (rg == 0 && k < Kc)
+    dst[((size_t)blockIdx.z * B + b) * Kc + k] = (part[0][kl] + part[1][kl]) + (part[2][kl] + part[3][kl]);
 }
+__global__ void linear_dx_combine_kernel(const float* part, float* dx, int64_t n, int chunks) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float s = 0.f;
+  for (int c = 0; c < chunks; ++c) s += part[(size_t)c * n + i];
+  dx[i] = s;
+}
+int linear_dx_chunks(int R) { return R > 2048 ? (R + 1023) / 1024 : 1; }
 hipError_t launch_linear_dx(int wdtype, const float* dy, int64_t dy_stride, const void* W, float* dx, int B, int R, int Kc,
-                            hipStream_t s) {
-  dim3 grid((Kc + 63) / 64, B);
+                            hipStream_t s, float* scratch) {
+  const int chunks = scratch ? linear_dx_chunks(R) : 1;
+  const int rchunk = (R + chunks - 1) / chunks;
+  float* dst = chunks > 1 ? scratch : dx;
+  dim3 grid((Kc + 63) / 64, B, chunks);
   switch (wdtype) {
-    case 0: hipLaunchKernelGGL(linear_dx_kernel<float>, grid, dim3(256), 0, s, dy, dy_stride, (const float*)W, dx, R, Kc); break;
-    case 1: hipLaunchKernelGGL(linear_dx_kernel<half_t>, grid, dim3(256), 0, s, dy, dy_stride, (const half_t*)W, dx, R, Kc); break;
-    case 2: hipLaunchKernelGGL(linear_dx_kernel<bf16_t>, grid, dim3(256), 0, s, dy, dy_stride, (const bf16_t*)W, dx, R, Kc); break;
+    case 0: hipLaunchKernelGGL(linear_dx_kernel<float>, grid, dim3(256), 0, s, dy, dy_stride, (const float*)W, dst, R, Kc, rchunk, B); break;
+    case 1: hipLaunchKernelGGL(linear_dx_kernel<half_t>, grid, dim3(256), 0, s, dy, dy_stride, (const half_t*)W, dst, R, Kc, rchunk, B); break;
+    case 2: hipLaunchKernelGGL(linear_dx_kernel<bf16_t>, grid, dim3(256), 0, s, dy, dy_stride, (const bf16_t*)W, dst, R, Kc, rchunk, B); break;
     default: return hipErrorInvalidValue;
+  }
+  if (chunks > 1) {
+    const int64_t n = (int64_t)B * Kc;
+    hipLaunchKernelGGL(linear_dx_combine_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, scratch, dx, n, chunks);
   }
   return hipGetLastError();
 }
@@ -652,7 +670,7 @@ hipError_t launch_final_bwd_data(int dtype, const FinalBwdArgs& a, hipStream_t s
 }
 // weight gradient: dW[o][c][tap] = sum_{b,p} deps[o][p] * a[p + tap - 1][c].  Block = 8 image rows; thread =
 // (channel c, pixel lane); partial[blk][o*9 + tap][c], partial bias sums in row Cout*9 (channel index = o).
-constexpr int kHeadRows = 8;
+constexpr int kHeadRows = 2;
 template <typename T>
 __global__ void __launch_bounds__(256) final_bwd_weight_kernel(const FinalBwdArgs a) {
   extern __shared__ float red[];  // [lanes][C]

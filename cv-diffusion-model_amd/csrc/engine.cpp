@@ -1161,11 +1161,14 @@ struct Back {
   }
   // FiLM Linear of every block: weight / bias gradients, and d(silu(temb)) summed over all FiLM rows
   void film_bwd(size_t dfilm, int F, int T, size_t dstemb) {
-    if (dry) return;
-    for (const IrbW& w : c->irbs)
-      chk(launch_linear_dw(p<float>(dfilm) + w.film_off, F, p<float>(tp->stemb), gp(w.p_first + 11), gp(w.p_first + 12), B,
-                           2 * w.hid, T, s));
-    chk(launch_linear_dx(0, p<float>(dfilm), F, wptr(c->film_w), p<float>(dstemb), B, F, T, s));
+    const size_t scratch = alloc((size_t)linear_dx_chunks(F) * B * T * 4);
+    if (!dry) {
+      for (const IrbW& w : c->irbs)
+        chk(launch_linear_dw(p<float>(dfilm) + w.film_off, F, p<float>(tp->stemb), gp(w.p_first + 11), gp(w.p_first + 12), B,
+                             2 * w.hid, T, s));
+      chk(launch_linear_dx(0, p<float>(dfilm), F, wptr(c->film_w), p<float>(dstemb), B, F, T, s, p<float>(scratch)));
+    }
+    ar->free(scratch);
   }
 
   // ---- whole UNet
@@ -1176,7 +1179,7 @@ struct Back {
     // output head
     const size_t da = alloc((size_t)M * C0 * es());
     {
-      const size_t part = alloc((size_t)B * (S / 8) * (g.out_channels * 9 + 1) * C0 * 4);
+      const size_t part = alloc((size_t)B * (S / 2) * (g.out_channels * 9 + 1) * C0 * 4);
       if (!dry) {
         FinalBwdArgs a{};
         a.deps = deps; a.w = wptr<float>(c->fin_w); a.h = p(tp->hlast.off); a.as = p<float>(tp->fin.as); a.ab = p<float>(tp->fin.ab);
@@ -1197,7 +1200,7 @@ struct Back {
     {
       const size_t g0 = take_grad(tp->h0);
       const int half = g.in_channels / 2;
-      const size_t part = alloc((size_t)B * (S / 8) * (g.in_channels * 9 + 1) * C0 * 4);
+      const size_t part = alloc((size_t)B * (S / 2) * (g.in_channels * 9 + 1) * C0 * 4);
       if (!dry) {
         InitBwdArgs a{};
         a.g = p(g0); a.x0 = tp->lat; a.x1 = tp->cond; a.c0 = half; a.c1 = g.in_channels - half; a.partial = p<float>(part);

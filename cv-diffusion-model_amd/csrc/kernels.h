@@ -318,8 +318,10 @@ hipError_t launch_dw_wgrad(int dtype, const DwWgradArgs& a, hipStream_t s);
 //   linear_dx:  dx[b][k] (=|+=) sum_r dy[b][r] * W[r][k]      (W is [R][Kc], T or fp32)
 //   linear_dw:  dW[r][k] = sum_b dy[b][r] * x[b][k],  db[r] = sum_b dy[b][r]      (fp32 outputs)
 //   dy rows have stride dy_stride (>= R) so that a slice of a wider table can be used in place
+//   scratch (optional, linear_dx_chunks(R)*B*Kc floats): lets a long R be cut into chunks that run in parallel
+int linear_dx_chunks(int R);
 hipError_t launch_linear_dx(int wdtype, const float* dy, int64_t dy_stride, const void* W, float* dx, int B, int R, int Kc,
-                            hipStream_t s);
+                            hipStream_t s, float* scratch = nullptr);
 hipError_t launch_linear_dw(const float* dy, int64_t dy_stride, const float* x, float* dW, float* db, int B, int R, int Kc,
                             hipStream_t s);
 //   SE gate: dpre2 = dgate * g*(1-g);  ReLU6 hidden: dpre1 = dr * [0 < r < 6];  SiLU: dx = dy * silu'(x)

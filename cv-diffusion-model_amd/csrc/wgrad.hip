@@ -118,6 +118,18 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgradArgs a, int rows_
   }
 }
 
+// Two-stage combine of the split partials.  Stage 1: kWgGroups blocks per 256 outputs, block g sums the splits
+// g, g + kWgGroups, ... (in that order) into row g of the partial buffer (it is the only reader of those rows).
+// Stage 2: one thread per output adds the kWgGroups rows in order and stores with the destination strides.
+constexpr int kWgGroups = 16;
+__global__ void __launch_bounds__(256) wgrad_reduce1_kernel(float* partial, int64_t nk, int msplit) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int g = blockIdx.y;
+  if (i >= nk || g >= msplit) return;
+  float s = 0.f;
+  for (int sp = g; sp < msplit; sp += kWgGroups) s += partial[(size_t)sp * nk + i];
+  partial[(size_t)g * nk + i] = s;
+}
 __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* partial, float* out, int N, int K, int msplit,
                                                            int64_t ldn, int64_t ldk, int64_t off) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -154,8 +166,13 @@ hipError_t launch_wgrad(int dtype, const WgradArgs& a, hipStream_t s) {
     default: return hipErrorInvalidValue;
   }
   const int64_t n = (int64_t)a.N * a.K;
+  int rows = a.msplit;
+  if (a.msplit > kWgGroups) {
+    hipLaunchKernelGGL(wgrad_reduce1_kernel, dim3((unsigned)((n + 255) / 256), kWgGroups), dim3(256), 0, s, a.partial, n, a.msplit);
+    rows = kWgGroups;
+  }
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a.partial, a.out, a.N, a.K,
-                     a.msplit, a.ldn, a.ldk, a.off);
+                     rows, a.ldn, a.ldk, a.off);
   return hipGetLastError();
 }
 

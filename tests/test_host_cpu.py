@@ -226,3 +226,52 @@ def test_deploy_loop_host_tables(golden):
     assert s.step_coefficients(739).clamp_x0 == 0          # the scheduler keeps x0 unclamped (lcm_scheduler.py:224-225)
     with pytest.raises(RuntimeError):
         loop.step(torch.zeros(1, 3, 8, 8), 739, torch.zeros(1, 3, 8, 8))   # CPU tensors: no fallback
+
+
+_GRAD_WORKER = r"""
+import importlib, os, sys, torch, torch.distributed as dist
+sys.path.insert(0, {root!r})
+M = importlib.import_module("cv-diffusion-model_amd")
+rank = int(sys.argv[1])
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:{port}", rank=rank, world_size=2)
+shapes = [(4, 3, 3, 3), (7,), (5, 2), (1,), (300, 11)]
+def make(r):
+    g = torch.Generator().manual_seed(100 + r)
+    return [torch.randn(s, generator=g) for s in shapes]
+mine, other = make(rank), make(1 - rank)
+want = [(a + b) / 2 for a, b in zip(mine, other)]
+# (1) gradients that alias one flat buffer (what the engine's backward hands to autograd): one collective
+flat = torch.cat([g.reshape(-1) for g in mine])
+params, o = [], 0
+for s_, g in zip(shapes, mine):
+    p = torch.nn.Parameter(torch.zeros(s_)); p.grad = flat[o:o + g.numel()].view(s_); o += g.numel(); params.append(p)
+assert M.all_reduce_gradients(params) == 1
+assert all(torch.allclose(p.grad, w, atol=1e-7) for p, w in zip(params, want))
+# (2) separately allocated gradients, small buckets: several collectives, same result; sum instead of mean
+params = []
+for s_, g in zip(shapes, mine):
+    p = torch.nn.Parameter(torch.zeros(s_)); p.grad = g.clone(); params.append(p)
+n = M.all_reduce_gradients(params, bucket_bytes=4096, average=False)
+assert n >= 2
+assert all(torch.allclose(p.grad, 2 * w, atol=1e-6) for p, w in zip(params, want))
+# (3) parameters without gradient are skipped
+params[1].grad = None
+M.all_reduce_gradients(params)
+dist.barrier()
+dist.destroy_process_group()
+print("ok")
+"""
+
+
+def test_all_reduce_gradients_world2_gloo(tmp_path):
+    """Data-parallel training (config 5): gradient averaging over ranks, flat-buffer fast path and bucketed path."""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    script = tmp_path / "gworker.py"
+    script.write_text(_GRAD_WORKER.format(root=ROOT, port=port))
+    procs = [subprocess.Popen([sys.executable, str(script), str(r)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+             for r in range(2)]
+    outs = [p.communicate(timeout=240)[0] for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0 and "ok" in o, o[-2000:]
+    assert M.all_reduce_gradients([torch.nn.Parameter(torch.zeros(2))]) == 0   # no process group: no-op

@@ -222,3 +222,31 @@ def test_deploy_loop_restatement_vs_reference(golden):
         assert out.dtype == g[f"step_{t}"].dtype and np.array_equal(out, g[f"step_{t}"])
     for t in (19, 499, 999):
         assert np.array_equal(S.deploy_add_noise(acp, g["x0"], g["add_noise_noise"], t), g[f"add_noise_{t}"])
+
+
+# ------------------------------------------------------------------ training step: autograd on the oracle vs the reference's
+def test_training_step_gradients_vs_reference(golden):
+    """The oracle is a functional restatement, so its backward pass is PyTorch autograd over the same ATen ops;
+    this pins it against gradients the reference model itself produced (tools/make_golden_train.py)."""
+    import torch.nn.functional as F
+    from oracle import scheduler_ref as S
+    g = golden("train_small64.npz")
+    spec = oracle.make_spec("small", 64)
+    sd = {k: v.clone().requires_grad_(True) for k, v in oracle.synth_state_dict(oracle.param_shapes(spec)).items()}
+    low = synth_input("train64.low", (2, 3, 64, 64), -1.0, -0.4)
+    normal = synth_input("train64.normal", (2, 3, 64, 64), -1, 1)
+    noise = synth_input("train64.noise", (2, 3, 64, 64), -2, 2)
+    t = torch.from_numpy(g["timesteps"])
+    tab = S.LCMTables.build(rescale_betas_zero_snr=True)
+    pred = oracle.unet_forward(sd, spec, torch.cat([S.add_noise(tab, normal, noise, t), low], 1), t)
+    loss = F.mse_loss(pred, noise)
+    loss.backward()
+    assert abs(loss.item() - float(g["loss"])) < 1e-6
+    keys = [str(k) for k in g["keys"]]
+    assert keys == list(sd.keys())
+    norms = np.array([sd[k].grad.double().norm().item() for k in keys])
+    assert np.max(np.abs(norms - g["grad_norms"]) / np.maximum(g["grad_norms"], 1e-12)) < 1e-4
+    for name in g.files:
+        if name.startswith("grad:"):
+            ref = g[name]
+            assert max_abs(sd[name[5:]].grad, ref) <= 2e-5 * np.abs(ref).max(), name
