@@ -275,62 +275,107 @@ hipError_t launch_add_into(int dtype, void* dst, const void* src, int64_t n, hip
 hipError_t launch_fill_zero(void* dst, int64_t bytes, hipStream_t s) { return hipMemsetAsync(dst, 0, (size_t)bytes, s); }
 
 // =============================================================================================
-// (5) depthwise weight gradient.  Block = strip of TX pixels x TY rows x CC channels; thread = one pixel
-// column x one channel vector, 9 x VEC running sums, combined over the strip's pixels through LDS tap by tap.
+// (5) depthwise weight gradient: dw[ky][kx][c] = sum_{b,y,x} dh2[y][x] * a2[y+ky-1][x+kx-1], dh2 = g*gs + gb,
+// a2 = relu6(h*as + ab).  Row-streaming like the forward depthwise kernel: a strip of TX pixels x TY rows x CC
+// channels per workgroup, activated rows of a2 pass through a 2-deep LDS ring (3 reads per row), each thread keeps
+// the dh2 values of its pixel for the rows R-1, R, R+1 in registers and 9 x VEC running sums, which are combined
+// over the strip's pixels through LDS at the end (fixed order).
 constexpr int kDwgTY = 32;
 static int dwg_tx(int W) { return (W % 32 == 0) ? 32 : ((W % 16 == 0) ? 16 : 8); }
 int dw_wgrad_strips(int H, int W) { return (W / dwg_tx(W)) * ((H + kDwgTY - 1) / kDwgTY); }
 
-template <typename T>
-__global__ void __launch_bounds__(256) dw_wgrad_kernel(const DwWgradArgs a, int TX) {
-  constexpr int VEC = Elem<T>::VEC, CC = 8 * VEC;
-  __shared__ float red[32][CC];
+template <typename T, int TX>
+__global__ void __launch_bounds__(8 * TX) dw_wgrad_kernel(const DwWgradArgs a) {
+  constexpr int VEC = Elem<T>::VEC, CC = 8 * VEC, PW = TX + 2;
+  typedef typename Elem<T>::vec_t vec_t;
+  __shared__ vec_t ring[2][PW * 8];
+  __shared__ float red[TX][CC];
   const int tid = threadIdx.x, cl = tid & 7, xl = tid >> 3;
   const int tiles_x = a.W / TX;
   const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
-  const int x = tx * TX + xl, y0 = ty * kDwgTY, y1 = min(y0 + kDwgTY, a.H);
+  const int x0 = tx * TX, y0 = ty * kDwgTY, TY = min(kDwgTY, a.H - y0);
   const int c0 = blockIdx.y * CC + cl * VEC, b = blockIdx.z;
-  const bool active = xl < TX;
-  float acc[9][VEC];
+  const bool is_halo = tid < 16;
+  const int hx = tid < 8 ? x0 - 1 : x0 + TX;
+  const bool hx_ok = is_halo && hx >= 0 && hx < a.W;
+  const int hslot = tid < 8 ? 0 : TX + 1;
+  float gs[VEC], gb[VEC], hs[VEC], hb[VEC];
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) {
+    const size_t o = (size_t)b * a.C + c0 + e;
+    gs[e] = a.gs ? a.gs[o] : 1.f;
+    gb[e] = a.gb ? a.gb[o] : 0.f;
+    hs[e] = a.as[o];
+    hb[e] = a.ab[o];
+  }
+  const T* gp = reinterpret_cast<const T*>(a.g) + (size_t)b * a.H * a.W * a.C + c0;
+  const T* hp = reinterpret_cast<const T*>(a.h) + (size_t)b * a.H * a.W * a.C + c0;
+  auto activate = [&](vec_t v) {
+    float f[VEC];
+    vec_to_f32<T>(v, f);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) f[e] = relu6f(f[e] * hs[e] + hb[e]);
+    return f32_to_vec<T>(f);
+  };
+  vec_t zero;
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) zero[e] = (T)0.f;
+  float acc[9][VEC], gprev[VEC], gcur[VEC], gnext[VEC];
 #pragma unroll
   for (int t = 0; t < 9; ++t)
 #pragma unroll
     for (int e = 0; e < VEC; ++e) acc[t][e] = 0.f;
-  if (active) {
-    float gs[VEC], gb[VEC], hs[VEC], hb[VEC];
+  auto load_g = [&](int y, float* out) {  // dh2 of this thread's pixel in row y (zero outside the strip)
+    if (y >= y0 && y < y0 + TY) {
+      float g[VEC];
+      ld_f32<T>(gp + ((size_t)y * a.W + x0 + xl) * a.C, g);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) out[e] = g[e] * gs[e] + gb[e];
+    } else {
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) out[e] = 0.f;
+    }
+  };
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) gprev[e] = gcur[e] = 0.f;
+  load_g(y0, gnext);
+  const int nrows = TY + 2;  // a2 rows y0-1 .. y0+TY
+  vec_t hpre = zero, hpre_h = zero;
+  auto issue = [&](int r) {
+    const int gy = y0 - 1 + r;
+    if (r < nrows && gy >= 0 && gy < a.H) {
+      const T* row = hp + (size_t)gy * a.W * a.C;
+      hpre = ld_vec<T>(row + (size_t)(x0 + xl) * a.C);
+      if (hx_ok) hpre_h = ld_vec<T>(row + (size_t)hx * a.C);
+    }
+  };
+  issue(0);
+  for (int r = 0; r < nrows; ++r) {
+    const int gy = y0 - 1 + r;
+    const bool row_ok = gy >= 0 && gy < a.H;
+    vec_t* buf = ring[r & 1];
+    buf[(xl + 1) * 8 + cl] = row_ok ? activate(hpre) : zero;
+    if (is_halo) buf[hslot * 8 + cl] = (row_ok && hx_ok) ? activate(hpre_h) : zero;
+    issue(r + 1);
+    float gload[VEC];
+    load_g(gy + 2, gload);
+    __syncthreads();
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      float f[VEC];
+      vec_to_f32<T>(buf[(xl + kx) * 8 + cl], f);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        acc[0 + kx][e] += gnext[e] * f[e];  // ky = 0: output row gy + 1
+        acc[3 + kx][e] += gcur[e] * f[e];   // ky = 1: output row gy
+        acc[6 + kx][e] += gprev[e] * f[e];  // ky = 2: output row gy - 1
+      }
+    }
 #pragma unroll
     for (int e = 0; e < VEC; ++e) {
-      const size_t o = (size_t)b * a.C + c0 + e;
-      gs[e] = a.gs ? a.gs[o] : 1.f;
-      gb[e] = a.gb ? a.gb[o] : 0.f;
-      hs[e] = a.as[o];
-      hb[e] = a.ab[o];
-    }
-    const T* gp = reinterpret_cast<const T*>(a.g) + (size_t)b * a.H * a.W * a.C + c0;
-    const T* hp = reinterpret_cast<const T*>(a.h) + (size_t)b * a.H * a.W * a.C + c0;
-    for (int y = y0; y < y1; ++y) {
-      float g[VEC];
-      ld_f32<T>(gp + ((size_t)y * a.W + x) * a.C, g);
-#pragma unroll
-      for (int e = 0; e < VEC; ++e) g[e] = g[e] * gs[e] + gb[e];
-#pragma unroll
-      for (int ky = 0; ky < 3; ++ky) {
-        const int yy = y + ky - 1;
-        if (yy < 0 || yy >= a.H) continue;
-#pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
-          const int xx = x + kx - 1;
-          if (xx < 0 || xx >= a.W) continue;
-          float h[VEC];
-          ld_f32<T>(hp + ((size_t)yy * a.W + xx) * a.C, h);
-#pragma unroll
-          for (int e = 0; e < VEC; ++e) {
-            // the value the forward depthwise kernel multiplied: ReLU6 output rounded to T
-            const float av = round_to<T>(relu6f(h[e] * hs[e] + hb[e]));
-            acc[ky * 3 + kx][e] += g[e] * av;
-          }
-        }
-      }
+      gprev[e] = gcur[e];
+      gcur[e] = gnext[e];
+      gnext[e] = gload[e];
     }
   }
   const size_t pbase = (((size_t)b * gridDim.x + blockIdx.x) * 9) * a.C + blockIdx.y * CC;
@@ -356,15 +401,21 @@ __global__ void dw_wgrad_reduce_kernel(const float* partial, float* out, int npa
   for (int p = 0; p < nparts; ++p) s += partial[((size_t)p * 9 + t) * C + c];
   out[(size_t)c * 9 + t] = s;
 }
+template <typename T>
+static void launch_dw_wgrad_t(const DwWgradArgs& a, dim3 grid, int TX, hipStream_t s) {
+  if (TX == 32) hipLaunchKernelGGL((dw_wgrad_kernel<T, 32>), grid, dim3(256), 0, s, a);
+  else if (TX == 16) hipLaunchKernelGGL((dw_wgrad_kernel<T, 16>), grid, dim3(128), 0, s, a);
+  else hipLaunchKernelGGL((dw_wgrad_kernel<T, 8>), grid, dim3(64), 0, s, a);
+}
 hipError_t launch_dw_wgrad(int dtype, const DwWgradArgs& a, hipStream_t s) {
   const int CC = dtype == 0 ? 32 : 64;
   if (a.C % CC || a.W % 8) return hipErrorInvalidValue;
   const int TX = dwg_tx(a.W);
   dim3 grid(dw_wgrad_strips(a.H, a.W), a.C / CC, a.B);
   switch (dtype) {
-    case 0: hipLaunchKernelGGL(dw_wgrad_kernel<float>, grid, dim3(256), 0, s, a, TX); break;
-    case 1: hipLaunchKernelGGL(dw_wgrad_kernel<half_t>, grid, dim3(256), 0, s, a, TX); break;
-    case 2: hipLaunchKernelGGL(dw_wgrad_kernel<bf16_t>, grid, dim3(256), 0, s, a, TX); break;
+    case 0: launch_dw_wgrad_t<float>(a, grid, TX, s); break;
+    case 1: launch_dw_wgrad_t<half_t>(a, grid, TX, s); break;
+    case 2: launch_dw_wgrad_t<bf16_t>(a, grid, TX, s); break;
     default: return hipErrorInvalidValue;
   }
   hipLaunchKernelGGL(dw_wgrad_reduce_kernel, dim3((9 * a.C + 255) / 256), dim3(256), 0, s, a.partial, a.out,

@@ -1,10 +1,10 @@
 // Weight gradient of the pointwise (1x1) convolutions and, one tap per launch, of the dense 3x3
 // convolutions: a TN GEMM  dW[n][k] = sum_m g[m][n] * A'[src(m)][k]  on MFMA.
 //
-// The contraction runs over pixels, which is the slow index of both NHWC operands, so each 64-row
-// chunk is transposed on its way into LDS ([channel][row]); a lane then reads 16 contiguous rows of
-// its channel per 32-row MFMA chunk (the same operand scheme as the forward GEMM, with the roles of
-// rows and channels swapped).  The rows are split over blockIdx.z; the fp32 partials are summed in
+// The contraction runs over pixels, which is the slow index of both NHWC operands.  Each 64-row chunk is
+// staged row-major in LDS with 16-byte stores and read back column-wise by the hardware transpose read
+// ds_read_b64_tr_b16 (gfx950), so a lane gets 16 consecutive rows of its channel per 32-row MFMA chunk (the
+// forward GEMM's operand scheme with the roles of rows and channels swapped); fp32 reads columns directly.  The rows are split over blockIdx.z; the fp32 partials are summed in
 // split order by a second kernel, so the result does not depend on scheduling.
 #include <string>
 
@@ -14,12 +14,34 @@ namespace llie {
 
 constexpr int kWgRows = 64;  // rows (pixels) per staged chunk
 
+// 16 contraction values (rows m = base .. base+15 of one channel column) for an MFMA operand, from a row-major
+// [row][channel] LDS image.  2-byte types: four ds_read_b64_tr_b16 (each hands a lane 4 consecutive rows of its
+// column; lane 4q+p of a 16-lane group addresses row q, columns 4p..4p+3 of the group's 4x16 block); fp32: 16
+// scalar reads (consecutive lanes = consecutive channels, conflict-free).
+typedef short s16x4 __attribute__((__vector_size__(4 * sizeof(short))));
+template <typename T>
+__device__ __forceinline__ void load_operand_rows(const T* img, int pitch, int row_base, int col_base, int lane, T* frag) {
+  if constexpr (sizeof(T) == 2) {
+    const int q = (lane & 15) >> 2, pp = lane & 3, cg = (lane >> 4) & 1;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const T* ptr = img + (row_base + 4 * j + q) * pitch + col_base + 16 * cg + 4 * pp;
+      const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(ptr));
+      *reinterpret_cast<s16x4*>(frag + 4 * j) = v;
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) frag[j] = img[(row_base + j) * pitch + col_base + (lane & 31)];
+  }
+}
+
 template <typename T>
 __global__ void __launch_bounds__(256) wgrad_kernel(const WgradArgs a, int rows_per_split) {
   constexpr int VEC = Elem<T>::VEC, VPR = 64 / VEC, RPP = 256 / VPR, NP = kWgRows / RPP;  // passes to load 64 rows x 64 channels
-  constexpr int PITCH = kWgRows + Elem<T>::VEC;
-  __shared__ __align__(16) T sG[64 * PITCH];
-  __shared__ __align__(16) T sA[64 * PITCH];
+  // row pitch: 2-byte T 192 B (q*48 banks apart: the 4-row blocks of a 32-lane half never collide), fp32 272 B
+  constexpr int PITCH = sizeof(T) == 2 ? 96 : 68;
+  __shared__ __align__(16) T sG[kWgRows * PITCH];
+  __shared__ __align__(16) T sA[kWgRows * PITCH];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wn = wave >> 1, wk = wave & 1;
   const int n0 = blockIdx.x * 64, k0 = blockIdx.y * 64;
@@ -56,8 +78,8 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgradArgs a, int rows_
 #pragma unroll
   for (int e = 0; e < VEC; ++e) zero[e] = (T)0.f;
 
-  for (int mc = 0; mc < rows_per_split; mc += kWgRows) {
-    vec_t gv[NP], av[NP];
+  vec_t gv[NP], av[NP];
+  auto fetch = [&](int mc) {
 #pragma unroll
     for (int ps = 0; ps < NP; ++ps) {
       const size_t m = m_begin + mc + ps * RPP + rl;
@@ -84,27 +106,24 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgradArgs a, int rows_
         }
       }
     }
-    __syncthreads();  // previous chunk's MFMA reads are done
+  };
+  fetch(0);
+  for (int mc = 0; mc < rows_per_split; mc += kWgRows) {
+    __syncthreads();  // previous chunk's operand reads are done
 #pragma unroll
     for (int ps = 0; ps < NP; ++ps) {
       const int r = ps * RPP + rl;
-#pragma unroll
-      for (int e = 0; e < VEC; ++e) {
-        sG[(cv + e) * PITCH + r] = gv[ps][e];
-        sA[(cv + e) * PITCH + r] = av[ps][e];
-      }
+      st_vec<T>(sG + r * PITCH + cv, gv[ps]);
+      st_vec<T>(sA + r * PITCH + cv, av[ps]);
     }
     __syncthreads();
+    if (mc + kWgRows < rows_per_split) fetch(mc + kWgRows);  // next chunk's global loads fly under the MFMAs
 #pragma unroll
     for (int ch = 0; ch < kWgRows / 32; ++ch) {
       T fa[16], fb[16];
-      const T* pa = sG + (wn * 32 + (lane & 31)) * PITCH + ch * 32 + (lane >> 5) * 16;
-      const T* pb = sA + (wk * 32 + (lane & 31)) * PITCH + ch * 32 + (lane >> 5) * 16;
-#pragma unroll
-      for (int q = 0; q < 16 / VEC; ++q) {
-        *reinterpret_cast<vec_t*>(&fa[q * VEC]) = *reinterpret_cast<const vec_t*>(pa + q * VEC);
-        *reinterpret_cast<vec_t*>(&fb[q * VEC]) = *reinterpret_cast<const vec_t*>(pb + q * VEC);
-      }
+      const int rb = ch * 32 + (lane >> 5) * 16;  // this lane half's 16 contraction rows of the 32-row MFMA chunk
+      load_operand_rows<T>(sG, PITCH, rb, wn * 32, lane, fa);
+      load_operand_rows<T>(sA, PITCH, rb, wk * 32, lane, fb);
       Mfma<T>::chunk(fa, fb, acc);
     }
   }
