@@ -900,16 +900,17 @@ struct Back {
     chk(launch_pw_gemm(dt, g, s));
   }
   struct Geo { int Ho, Wo, Hi, Wi, stride, dy, dx; };
-  void wgrad(size_t g, int N, const GemmSeg* segs, int nseg, int K, Geo geo, float* out, int64_t ldn, int64_t ldk, int64_t off) {
+  void wgrad(size_t g, int N, const GemmSeg* segs, int nseg, int K, Geo geo, float* out, int64_t ldn, int64_t ldk, int64_t off,
+             int ntap = 1) {
     const int M = B * geo.Ho * geo.Wo;
-    const int ms = wgrad_msplit(M, N, K);
-    const size_t part = alloc((size_t)ms * N * K * 4);
+    const int ms = wgrad_msplit(M, N, K, ntap);
+    const size_t part = alloc((size_t)ms * ntap * N * K * 4);
     if (!dry) {
       WgradArgs a{};
       a.g = p(g); a.N = N; a.nseg = nseg; a.K = K;
       for (int i = 0; i < nseg; ++i) a.seg[i] = segs[i];
       a.B = B; a.Ho = geo.Ho; a.Wo = geo.Wo; a.Hi = geo.Hi; a.Wi = geo.Wi; a.stride = geo.stride; a.dy = geo.dy; a.dx = geo.dx;
-      a.partial = p<float>(part); a.out = out; a.ldn = ldn; a.ldk = ldk; a.off = off; a.msplit = ms;
+      a.partial = p<float>(part); a.out = out; a.ldn = ldn; a.ldk = ldk; a.off = off; a.msplit = ms; a.ntap = ntap;
       chk(launch_wgrad(dt, a, s));
     }
     ar->free(part);
@@ -1121,10 +1122,10 @@ struct Back {
       ar->free(slab); ar->free(S);
     }
     const Tens& src = r.up ? r.u : r.x;  // what the conv itself read
-    for (int tap = 0; tap < 9; ++tap) {
+    {
       GemmSeg sg{dry ? nullptr : p(src.off), C, nullptr, nullptr, 0, ACT_NONE};
-      const Geo geo{Ho, Wo, src.H, src.W, r.up ? 1 : 2, tap / 3 - 1, tap % 3 - 1};
-      wgrad(dY, C, &sg, 1, C, geo, gp(pf + 0), (int64_t)C * 9, 9, tap);
+      const Geo geo{Ho, Wo, src.H, src.W, r.up ? 1 : 2, 0, 0};
+      wgrad(dY, C, &sg, 1, C, geo, gp(pf + 0), (int64_t)C * 9, 9, 0, 9);
     }
     // input gradient: stride-1 conv with flipped / transposed weights over dY (zero-dilated for the stride-2 conv)
     size_t din = dY;

@@ -295,11 +295,12 @@ struct WgradArgs {
   const void* g; int N;
   GemmSeg seg[3]; int nseg; int K;
   int B, Ho, Wo, Hi, Wi, stride, dy, dx;
-  float* partial;      // [msplit][N][K] scratch
+  int ntap;            // 1, or 9: all taps of a 3x3 weight in one launch (dy, dx ignored; tap t lands at off + t)
+  float* partial;      // [msplit][ntap][N][K] scratch
   float* out; int64_t ldn, ldk, off;
   int msplit;
 };
-int wgrad_msplit(int M, int N, int K);
+int wgrad_msplit(int M, int N, int K, int ntap);
 hipError_t launch_wgrad(int dtype, const WgradArgs& a, hipStream_t s);
 
 // (5) depthwise 3x3 weight gradient: dw[c][tap] (reference layout [C][1][3][3]) =

@@ -44,7 +44,11 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgradArgs a, int rows_
   __shared__ __align__(16) T sA[kWgRows * PITCH];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wn = wave >> 1, wk = wave & 1;
-  const int n0 = blockIdx.x * 64, k0 = blockIdx.y * 64;
+  const int ktiles = (a.K + 63) / 64;
+  const int tap = blockIdx.y / ktiles;  // ntap == 9: all taps of a 3x3 weight in one launch (tap-major grid.y, so the
+                                        // nine workgroups that share a g chunk are scheduled together and hit L2)
+  const int n0 = blockIdx.x * 64, k0 = (blockIdx.y % ktiles) * 64;
+  const int tdy = a.ntap == 9 ? tap / 3 - 1 : a.dy, tdx = a.ntap == 9 ? tap % 3 - 1 : a.dx;
   const int cv = (tid % VPR) * VEC, rl = tid / VPR;
   const int P = a.Ho * a.Wo;
   const size_t m_begin = (size_t)blockIdx.z * rows_per_split;
@@ -88,7 +92,7 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgradArgs a, int rows_
       if (aptr) {
         const int b = (int)(m / P);
         const int pix = (int)(m % P);
-        const int y = (pix / a.Wo) * a.stride + a.dy, x = (pix % a.Wo) * a.stride + a.dx;
+        const int y = (pix / a.Wo) * a.stride + tdy, x = (pix % a.Wo) * a.stride + tdx;
         if (y >= 0 && y < a.Hi && x >= 0 && x < a.Wi) {
           vec_t v = ld_vec<T>(aptr + (((size_t)b * a.Hi + y) * a.Wi + x) * ach + aoff);
           if (aas || aact != ACT_NONE) {
@@ -128,7 +132,7 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgradArgs a, int rows_
     }
   }
   // D[row = n (A-operand row)][col = k (B-operand row)]
-  float* out = a.partial + (size_t)blockIdx.z * a.N * a.K;
+  float* out = a.partial + ((size_t)blockIdx.z * a.ntap + tap) * a.N * a.K;
   const int k = k0 + wk * 32 + (lane & 31);
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
@@ -149,19 +153,22 @@ __global__ void __launch_bounds__(256) wgrad_reduce1_kernel(float* partial, int6
   for (int sp = g; sp < msplit; sp += kWgGroups) s += partial[(size_t)sp * nk + i];
   partial[(size_t)g * nk + i] = s;
 }
-__global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* partial, float* out, int N, int K, int msplit,
+__global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* partial, float* out, int N, int K, int ntap, int msplit,
                                                            int64_t ldn, int64_t ldk, int64_t off) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= (int64_t)N * K) return;
+  const int64_t tot = (int64_t)ntap * N * K;
+  if (i >= tot) return;
   float s = 0.f;
-  for (int sp = 0; sp < msplit; ++sp) s += partial[(size_t)sp * N * K + i];
-  const int n = (int)(i / K), k = (int)(i % K);
-  out[(size_t)n * ldn + (size_t)k * ldk + off] = s;
+  for (int sp = 0; sp < msplit; ++sp) s += partial[(size_t)sp * tot + i];
+  const int tap = (int)(i / ((int64_t)N * K));
+  const int64_t j = i % ((int64_t)N * K);
+  const int n = (int)(j / K), k = (int)(j % K);
+  out[(size_t)n * ldn + (size_t)k * ldk + off + (ntap == 9 ? tap : 0)] = s;
 }
 
 // number of row splits: enough workgroups to fill the GPU, each split a multiple of 64 rows
-int wgrad_msplit(int M, int N, int K) {
-  const int tiles = ((N + 63) / 64) * ((K + 63) / 64);
+int wgrad_msplit(int M, int N, int K, int ntap) {
+  const int tiles = ((N + 63) / 64) * ((K + 63) / 64) * ntap;
   int ms = 1;
   while (tiles * ms < 2048 && M % (ms * 2 * kWgRows) == 0 && M / (ms * 2) >= 256) ms *= 2;
   return ms;
@@ -176,7 +183,8 @@ hipError_t launch_wgrad(int dtype, const WgradArgs& a, hipStream_t s) {
     k += a.seg[i].ch;
   }
   if (k != a.K) return hipErrorInvalidValue;
-  dim3 grid((a.N + 63) / 64, (a.K + 63) / 64, a.msplit);
+  if (a.ntap != 1 && a.ntap != 9) return hipErrorInvalidValue;
+  dim3 grid((a.N + 63) / 64, ((a.K + 63) / 64) * a.ntap, a.msplit);
   const int rps = M / a.msplit;
   switch (dtype) {
     case 0: hipLaunchKernelGGL(wgrad_kernel<float>, grid, dim3(256), 0, s, a, rps); break;
@@ -184,14 +192,14 @@ hipError_t launch_wgrad(int dtype, const WgradArgs& a, hipStream_t s) {
     case 2: hipLaunchKernelGGL(wgrad_kernel<bf16_t>, grid, dim3(256), 0, s, a, rps); break;
     default: return hipErrorInvalidValue;
   }
-  const int64_t n = (int64_t)a.N * a.K;
+  const int64_t n = (int64_t)a.ntap * a.N * a.K;
   int rows = a.msplit;
   if (a.msplit > kWgGroups) {
     hipLaunchKernelGGL(wgrad_reduce1_kernel, dim3((unsigned)((n + 255) / 256), kWgGroups), dim3(256), 0, s, a.partial, n, a.msplit);
     rows = kWgGroups;
   }
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a.partial, a.out, a.N, a.K,
-                     rows, a.ldn, a.ldk, a.off);
+                     a.ntap, rows, a.ldn, a.ldk, a.off);
   return hipGetLastError();
 }
 
