@@ -201,12 +201,14 @@ hipError_t launch_gn_param_grad(const GnParamGradArgs& a, hipStream_t s) {
 template <typename T>
 __global__ void __launch_bounds__(256) gn_bwd_apply_kernel(const GnApplyArgs a) {
   constexpr int VEC = Elem<T>::VEC;
-  const int C = a.c0 + a.c1, vpr = C / VEC;
-  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= (size_t)a.M * vpr) return;
-  const size_t m = idx / vpr;
-  const int c = (int)(idx % vpr) * VEC;
-  const int b = (int)(m / a.P);
+  const int C = a.c0 + a.c1;
+  const unsigned vpr = C / VEC;
+  const unsigned idx = blockIdx.x * 256u + threadIdx.x;  // 32-bit index math (the launcher checks the range)
+  if (idx >= (unsigned)a.M * vpr) return;
+  const unsigned mi = idx / vpr;
+  const size_t m = mi;
+  const int c = (int)(idx - mi * vpr) * VEC;
+  const int b = (int)(mi / (unsigned)a.P);
   const bool second = c >= a.c0;
   const int xc = second ? a.c1 : a.c0, xo = second ? c - a.c0 : c;
   const T* xp = reinterpret_cast<const T*>(second ? a.x1 : a.x0);
@@ -237,6 +239,7 @@ hipError_t launch_gn_bwd_apply(int dtype, const GnApplyArgs& a, hipStream_t s) {
   const int C = a.c0 + a.c1;
   if (C % 32 || a.c0 % 32 || a.M % a.P) return hipErrorInvalidValue;
   const size_t vecs = (size_t)a.M * C / (dtype == 0 ? 4 : 8);
+  if (vecs >= (1ull << 31)) return hipErrorInvalidValue;
   dim3 grid((unsigned)((vecs + 255) / 256));
   switch (dtype) {
     case 0: hipLaunchKernelGGL(gn_bwd_apply_kernel<float>, grid, dim3(256), 0, s, a); break;

@@ -903,7 +903,7 @@ struct Back {
   void wgrad(size_t g, int N, const GemmSeg* segs, int nseg, int K, Geo geo, float* out, int64_t ldn, int64_t ldk, int64_t off,
              int ntap = 1) {
     const int M = B * geo.Ho * geo.Wo;
-    const int ms = wgrad_msplit(M, N, K, ntap);
+    const int ms = wgrad_msplit(dt, M, N, K, ntap);
     const size_t part = alloc((size_t)ms * ntap * N * K * 4);
     if (!dry) {
       WgradArgs a{};

@@ -300,7 +300,7 @@ struct WgradArgs {
   float* out; int64_t ldn, ldk, off;
   int msplit;
 };
-int wgrad_msplit(int M, int N, int K, int ntap);
+int wgrad_msplit(int dtype, int M, int N, int K, int ntap);
 hipError_t launch_wgrad(int dtype, const WgradArgs& a, hipStream_t s);
 
 // (5) depthwise 3x3 weight gradient: dw[c][tap] (reference layout [C][1][3][3]) =

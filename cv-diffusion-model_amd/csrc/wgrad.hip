@@ -35,19 +35,22 @@ __device__ __forceinline__ void load_operand_rows(const T* img, int pitch, int r
   }
 }
 
-template <typename T>
+// WT = 32-wide blocks per wave and dimension: the workgroup tile is (64*WT) x (64*WT) outputs.  WT = 2 halves the
+// re-reads of g (once per k-tile) and A' (once per n-tile) for the wide layers.
+template <typename T, int WT>
 __global__ void __launch_bounds__(256) wgrad_kernel(const WgradArgs a, int rows_per_split) {
-  constexpr int VEC = Elem<T>::VEC, VPR = 64 / VEC, RPP = 256 / VPR, NP = kWgRows / RPP;  // passes to load 64 rows x 64 channels
-  // row pitch: 2-byte T 192 B (q*48 banks apart: the 4-row blocks of a 32-lane half never collide), fp32 272 B
-  constexpr int PITCH = sizeof(T) == 2 ? 96 : 68;
+  constexpr int TILE = 64 * WT;
+  constexpr int VEC = Elem<T>::VEC, VPR = TILE / VEC, RPP = 256 / VPR, NP = kWgRows / RPP;  // passes to load 64 rows x TILE channels
+  // row pitch in bytes = 64 (mod 256): the 4-row blocks a 32-lane half reads with ds_read_b64_tr_b16 land 16 banks apart
+  constexpr int PITCH = sizeof(T) == 2 ? TILE + 32 : TILE + 4;
   __shared__ __align__(16) T sG[kWgRows * PITCH];
   __shared__ __align__(16) T sA[kWgRows * PITCH];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wn = wave >> 1, wk = wave & 1;
-  const int ktiles = (a.K + 63) / 64;
+  const int ktiles = (a.K + TILE - 1) / TILE;
   const int tap = blockIdx.y / ktiles;  // ntap == 9: all taps of a 3x3 weight in one launch (tap-major grid.y, so the
                                         // nine workgroups that share a g chunk are scheduled together and hit L2)
-  const int n0 = blockIdx.x * 64, k0 = (blockIdx.y % ktiles) * 64;
+  const int n0 = blockIdx.x * TILE, k0 = (blockIdx.y % ktiles) * TILE;
   const int tdy = a.ntap == 9 ? tap / 3 - 1 : a.dy, tdx = a.ntap == 9 ? tap % 3 - 1 : a.dx;
   const int cv = (tid % VPR) * VEC, rl = tid / VPR;
   const int P = a.Ho * a.Wo;
@@ -74,36 +77,61 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgradArgs a, int rows_
   const bool g_ok = n0 + cv < a.N;
   const T* gp = reinterpret_cast<const T*>(a.g);
 
-  f32x16 acc;
+  f32x16 acc[WT][WT];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  for (int i = 0; i < WT; ++i)
+#pragma unroll
+    for (int j = 0; j < WT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   typedef typename Elem<T>::vec_t vec_t;
   vec_t zero;
 #pragma unroll
   for (int e = 0; e < VEC; ++e) zero[e] = (T)0.f;
 
+  // Every 64-row chunk lies inside one image (P % 64 == 0, splits start on multiples of 64), so the image index and
+  // the prologue's per-(image, channel) affine are chunk-uniform: 32-bit index math once per chunk, the affine is
+  // reloaded only when the image changes.  1x1 layers (source pixel == output pixel) skip the pixel decomposition.
+  const int chunks_per_image = P / kWgRows;
+  const int chunk0 = (int)(m_begin / kWgRows);
+  const bool plain = a.ntap == 1 && a.stride == 1 && a.dy == 0 && a.dx == 0 && a.Hi == a.Ho && a.Wi == a.Wo;
+  float sc[VEC], sh[VEC];
+  int cur_b = -1;
   vec_t gv[NP], av[NP];
   auto fetch = [&](int mc) {
+    const int chunk = chunk0 + mc / kWgRows;
+    const int b = chunk / chunks_per_image;
+    const int pix0 = (chunk - b * chunks_per_image) * kWgRows;
+    if (aptr && aas && b != cur_b) {
+      cur_b = b;
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        sc[e] = aas[(size_t)b * ald + aoff + e];
+        sh[e] = aab ? aab[(size_t)b * ald + aoff + e] : 0.f;
+      }
+    }
+    const size_t mrow0 = (size_t)chunk * kWgRows;
 #pragma unroll
     for (int ps = 0; ps < NP; ++ps) {
-      const size_t m = m_begin + mc + ps * RPP + rl;
-      gv[ps] = g_ok ? ld_vec<T>(gp + m * a.N + n0 + cv) : zero;
+      const int r = ps * RPP + rl;
+      gv[ps] = g_ok ? ld_vec<T>(gp + (mrow0 + r) * a.N + n0 + cv) : zero;
       av[ps] = zero;
       if (aptr) {
-        const int b = (int)(m / P);
-        const int pix = (int)(m % P);
-        const int y = (pix / a.Wo) * a.stride + tdy, x = (pix % a.Wo) * a.stride + tdx;
-        if (y >= 0 && y < a.Hi && x >= 0 && x < a.Wi) {
-          vec_t v = ld_vec<T>(aptr + (((size_t)b * a.Hi + y) * a.Wi + x) * ach + aoff);
+        bool ok = true;
+        size_t src = mrow0 + r;  // plain: same pixel
+        if (!plain) {
+          const int pix = pix0 + r;
+          const int y = (pix / a.Wo) * a.stride + tdy, x = (pix % a.Wo) * a.stride + tdx;
+          ok = y >= 0 && y < a.Hi && x >= 0 && x < a.Wi;
+          src = ((size_t)b * a.Hi + y) * a.Wi + x;
+        }
+        if (ok) {
+          vec_t v = ld_vec<T>(aptr + src * ach + aoff);
           if (aas || aact != ACT_NONE) {
             float f[VEC];
             vec_to_f32<T>(v, f);
 #pragma unroll
-            for (int e = 0; e < VEC; ++e) {
-              float t = f[e];
-              if (aas) t = t * aas[(size_t)b * ald + aoff + e] + (aab ? aab[(size_t)b * ald + aoff + e] : 0.f);
-              f[e] = apply_act(t, aact);
-            }
+            for (int e = 0; e < VEC; ++e) f[e] = apply_act(aas ? f[e] * sc[e] + sh[e] : f[e], aact);
             v = f32_to_vec<T>(f);
           }
           av[ps] = v;
@@ -124,21 +152,32 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgradArgs a, int rows_
     if (mc + kWgRows < rows_per_split) fetch(mc + kWgRows);  // next chunk's global loads fly under the MFMAs
 #pragma unroll
     for (int ch = 0; ch < kWgRows / 32; ++ch) {
-      T fa[16], fb[16];
+      T fa[WT][16], fb[WT][16];
       const int rb = ch * 32 + (lane >> 5) * 16;  // this lane half's 16 contraction rows of the 32-row MFMA chunk
-      load_operand_rows<T>(sG, PITCH, rb, wn * 32, lane, fa);
-      load_operand_rows<T>(sA, PITCH, rb, wk * 32, lane, fb);
-      Mfma<T>::chunk(fa, fb, acc);
+#pragma unroll
+      for (int i = 0; i < WT; ++i) {
+        load_operand_rows<T>(sG, PITCH, rb, (wn * WT + i) * 32, lane, fa[i]);
+        load_operand_rows<T>(sA, PITCH, rb, (wk * WT + i) * 32, lane, fb[i]);
+      }
+#pragma unroll
+      for (int i = 0; i < WT; ++i)
+#pragma unroll
+        for (int j = 0; j < WT; ++j) Mfma<T>::chunk(fa[i], fb[j], acc[i][j]);
     }
   }
   // D[row = n (A-operand row)][col = k (B-operand row)]
   float* out = a.partial + ((size_t)blockIdx.z * a.ntap + tap) * a.N * a.K;
-  const int k = k0 + wk * 32 + (lane & 31);
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int n = n0 + wn * 32 + mfma_row(r, lane);
-    if (n < a.N && k < a.K) out[(size_t)n * a.K + k] = acc[r];
-  }
+  for (int i = 0; i < WT; ++i)
+#pragma unroll
+    for (int j = 0; j < WT; ++j) {
+      const int k = k0 + (wk * WT + j) * 32 + (lane & 31);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int n = n0 + (wn * WT + i) * 32 + mfma_row(r, lane);
+        if (n < a.N && k < a.K) out[(size_t)n * a.K + k] = acc[i][j][r];
+      }
+    }
 }
 
 // Two-stage combine of the split partials.  Stage 1: kWgGroups blocks per 256 outputs, block g sums the splits
@@ -167,8 +206,11 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* partial,
 }
 
 // number of row splits: enough workgroups to fill the GPU, each split a multiple of 64 rows
-int wgrad_msplit(int M, int N, int K, int ntap) {
-  const int tiles = ((N + 63) / 64) * ((K + 63) / 64) * ntap;
+// 128x128 tiles for the wide layers of the 2-byte engines (fp32 tiles would not fit the 64 KB static LDS)
+static int wgrad_tile(int dtype, int N, int K) { return (dtype != 0 && N >= 128 && K > 64) ? 128 : 64; }
+int wgrad_msplit(int dtype, int M, int N, int K, int ntap) {
+  const int t = wgrad_tile(dtype, N, K);
+  const int tiles = ((N + t - 1) / t) * ((K + t - 1) / t) * ntap;
   int ms = 1;
   while (tiles * ms < 2048 && M % (ms * 2 * kWgRows) == 0 && M / (ms * 2) >= 256) ms *= 2;
   return ms;
@@ -184,12 +226,19 @@ hipError_t launch_wgrad(int dtype, const WgradArgs& a, hipStream_t s) {
   }
   if (k != a.K) return hipErrorInvalidValue;
   if (a.ntap != 1 && a.ntap != 9) return hipErrorInvalidValue;
-  dim3 grid((a.N + 63) / 64, ((a.K + 63) / 64) * a.ntap, a.msplit);
+  const int t = wgrad_tile(dtype, a.N, a.K);
+  dim3 grid((a.N + t - 1) / t, ((a.K + t - 1) / t) * a.ntap, a.msplit);
   const int rps = M / a.msplit;
   switch (dtype) {
-    case 0: hipLaunchKernelGGL(wgrad_kernel<float>, grid, dim3(256), 0, s, a, rps); break;
-    case 1: hipLaunchKernelGGL(wgrad_kernel<half_t>, grid, dim3(256), 0, s, a, rps); break;
-    case 2: hipLaunchKernelGGL(wgrad_kernel<bf16_t>, grid, dim3(256), 0, s, a, rps); break;
+    case 0: hipLaunchKernelGGL((wgrad_kernel<float, 1>), grid, dim3(256), 0, s, a, rps); break;
+    case 1:
+      if (t == 128) hipLaunchKernelGGL((wgrad_kernel<half_t, 2>), grid, dim3(256), 0, s, a, rps);
+      else hipLaunchKernelGGL((wgrad_kernel<half_t, 1>), grid, dim3(256), 0, s, a, rps);
+      break;
+    case 2:
+      if (t == 128) hipLaunchKernelGGL((wgrad_kernel<bf16_t, 2>), grid, dim3(256), 0, s, a, rps);
+      else hipLaunchKernelGGL((wgrad_kernel<bf16_t, 1>), grid, dim3(256), 0, s, a, rps);
+      break;
     default: return hipErrorInvalidValue;
   }
   const int64_t n = (int64_t)a.ntap * a.N * a.K;
