@@ -18,7 +18,8 @@ __global__ void __launch_bounds__(256) bwd_mask_reduce_kernel(const BwdMaskArgs 
   const int tid = threadIdx.x, cv = tid % VPR, rl = tid / VPR;
   const int c = blockIdx.y * CB + cv * VEC;
   const size_t m0 = (size_t)blockIdx.x * 64;
-  const int b = (int)(m0 / a.P), tile = (int)((m0 % a.P) / 64), ntiles = a.P / 64;
+  const int ntiles = a.P / 64;
+  const int b = (int)(blockIdx.x / (unsigned)ntiles), tile = (int)(blockIdx.x - (unsigned)b * ntiles);
   float s1[VEC], s2[VEC];
 #pragma unroll
   for (int e = 0; e < VEC; ++e) s1[e] = s2[e] = 0.f;
@@ -277,6 +278,18 @@ hipError_t launch_add_into(int dtype, void* dst, const void* src, int64_t n, hip
 }
 hipError_t launch_fill_zero(void* dst, int64_t bytes, hipStream_t s) { return hipMemsetAsync(dst, 0, (size_t)bytes, s); }
 
+// First stage of a two-stage combine of `nparts` partial rows of `nk` floats: block (x, g) adds rows g, g + G, ...
+// (in that order) into row g, of which it is the only reader; the caller then combines the first G rows.
+constexpr int kPartGroups = 16;
+__global__ void __launch_bounds__(256) partial_groups_kernel(float* partial, int64_t nk, int nparts) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int g = blockIdx.y;
+  if (i >= nk || g >= nparts) return;
+  float s = 0.f;
+  for (int sp = g; sp < nparts; sp += kPartGroups) s += partial[(size_t)sp * nk + i];
+  partial[(size_t)g * nk + i] = s;
+}
+
 // =============================================================================================
 // (5) depthwise weight gradient: dw[ky][kx][c] = sum_{b,y,x} dh2[y][x] * a2[y+ky-1][x+kx-1], dh2 = g*gs + gb,
 // a2 = relu6(h*as + ab).  Row-streaming like the forward depthwise kernel: a strip of TX pixels x TY rows x CC
@@ -421,8 +434,12 @@ hipError_t launch_dw_wgrad(int dtype, const DwWgradArgs& a, hipStream_t s) {
     case 2: launch_dw_wgrad_t<bf16_t>(a, grid, TX, s); break;
     default: return hipErrorInvalidValue;
   }
-  hipLaunchKernelGGL(dw_wgrad_reduce_kernel, dim3((9 * a.C + 255) / 256), dim3(256), 0, s, a.partial, a.out,
-                     a.B * (int)grid.x, a.C);
+  int nparts = a.B * (int)grid.x;
+  if (nparts > kPartGroups) {
+    hipLaunchKernelGGL(partial_groups_kernel, dim3((9 * a.C + 255) / 256, kPartGroups), dim3(256), 0, s, a.partial, (int64_t)9 * a.C, nparts);
+    nparts = kPartGroups;
+  }
+  hipLaunchKernelGGL(dw_wgrad_reduce_kernel, dim3((9 * a.C + 255) / 256), dim3(256), 0, s, a.partial, a.out, nparts, a.C);
   return hipGetLastError();
 }
 
@@ -454,7 +471,7 @@ __global__ void linear_dx_combine_kernel(const float* part, float* dx, int64_t n
   for (int c = 0; c < chunks; ++c) s += part[(size_t)c * n + i];
   dx[i] = s;
 }
-int linear_dx_chunks(int R) { return R > 2048 ? (R + 1023) / 1024 : 1; }
+int linear_dx_chunks(int R) { return R > 256 ? (R + 127) / 128 : 1; }
 hipError_t launch_linear_dx(int wdtype, const float* dy, int64_t dy_stride, const void* W, float* dx, int B, int R, int Kc,
                             hipStream_t s, float* scratch) {
   const int chunks = scratch ? linear_dx_chunks(R) : 1;
@@ -759,31 +776,25 @@ __global__ void __launch_bounds__(256) final_bwd_weight_kernel(const FinalBwdArg
       }
     }
   }
+  // all sums of the block through LDS at once: red[lane][row][c]; the bias row holds bsum[o] at channel index o
   const int rows = a.Cout * 9 + 1;
   float* out = a.partial + ((size_t)b * gridDim.x + blockIdx.x) * rows * a.C;
 #pragma unroll
   for (int j = 0; j < 36; ++j) {
-    if (j >= a.Cout * 9) break;  // uniform
-    __syncthreads();
-    red[pl * a.C + c] = acc[j];
-    __syncthreads();
-    if (pl == 0) {
-      float v = 0.f;
-      for (int q = 0; q < lanes; ++q) v += red[q * a.C + c];
-      out[(size_t)j * a.C + c] = v;
-    }
+    if (j >= a.Cout * 9) break;
+    red[((size_t)pl * rows + j) * a.C + c] = acc[j];
   }
+  if (c == 0) {  // every thread of a lane saw the same pixels: channel 0's thread stores the lane's bias sums
 #pragma unroll
-  for (int o = 0; o < 4; ++o) {
-    if (o >= a.Cout) break;  // uniform
-    __syncthreads();
-    red[pl * a.C + c] = c == 0 ? bsum[o] : 0.f;
-    __syncthreads();
-    if (tid == 0) {
-      float v = 0.f;
-      for (int q = 0; q < lanes; ++q) v += red[q * a.C];
-      out[(size_t)a.Cout * 9 * a.C + o] = v;
-    }
+    for (int o = 0; o < 4; ++o)
+      if (o < a.Cout) red[((size_t)pl * rows + a.Cout * 9) * a.C + o] = bsum[o];
+  }
+  __syncthreads();
+  for (int i = tid; i < rows * a.C; i += 256) {
+    if (i >= a.Cout * 9 * a.C && i - a.Cout * 9 * a.C >= a.Cout) continue;  // unused tail of the bias row
+    float v = 0.f;
+    for (int q = 0; q < lanes; ++q) v += red[(size_t)q * rows * a.C + i];
+    out[i] = v;
   }
 }
 __global__ void final_bwd_weight_reduce_kernel(const float* partial, float* dw, float* dbias, int nparts, int C, int Cout) {
@@ -805,7 +816,7 @@ __global__ void final_bwd_weight_reduce_kernel(const float* partial, float* dw, 
 hipError_t launch_final_bwd_weight(int dtype, const FinalBwdArgs& a, hipStream_t s) {
   if (a.C > 256 || 256 % a.C || a.Cout > 4 || a.H % kHeadRows) return hipErrorInvalidValue;
   dim3 grid(a.H / kHeadRows, a.B);
-  const size_t lds = 256 * sizeof(float);
+  const size_t lds = (size_t)256 * (a.Cout * 9 + 1) * sizeof(float);  // [256 / C lanes][rows][C]
   switch (dtype) {
     case 0: hipLaunchKernelGGL(final_bwd_weight_kernel<float>, grid, dim3(256), lds, s, a); break;
     case 1: hipLaunchKernelGGL(final_bwd_weight_kernel<half_t>, grid, dim3(256), lds, s, a); break;
@@ -813,8 +824,14 @@ hipError_t launch_final_bwd_weight(int dtype, const FinalBwdArgs& a, hipStream_t
     default: return hipErrorInvalidValue;
   }
   const int n = a.Cout * 9 * a.C + a.Cout;
+  int nparts = a.B * (a.H / kHeadRows);
+  const int64_t nk = (int64_t)(a.Cout * 9 + 1) * a.C;
+  if (nparts > kPartGroups) {
+    hipLaunchKernelGGL(partial_groups_kernel, dim3((unsigned)((nk + 255) / 256), kPartGroups), dim3(256), 0, s, a.partial, nk, nparts);
+    nparts = kPartGroups;
+  }
   hipLaunchKernelGGL(final_bwd_weight_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, s, a.partial, a.dw, a.dbias,
-                     a.B * (a.H / kHeadRows), a.C, a.Cout);
+                     nparts, a.C, a.Cout);
   return hipGetLastError();
 }
 
@@ -850,19 +867,19 @@ __global__ void __launch_bounds__(256) init_bwd_weight_kernel(const InitBwdArgs 
       }
     }
   }
+  // all (row, channel) sums of the block through LDS at once: red[lane][row][co]
   const int rows = Cin * 9 + 1;
   float* out = a.partial + ((size_t)b * gridDim.x + blockIdx.x) * rows * a.Cout;
 #pragma unroll
   for (int j = 0; j < 73; ++j) {
-    if (j >= rows) break;  // uniform
-    __syncthreads();
-    red[pl * a.Cout + co] = j < Cin * 9 ? acc[j < 72 ? j : 0] : bsum;
-    __syncthreads();
-    if (pl == 0) {
-      float v = 0.f;
-      for (int q = 0; q < lanes; ++q) v += red[q * a.Cout + co];
-      out[(size_t)j * a.Cout + co] = v;
-    }
+    if (j >= rows) break;
+    red[((size_t)pl * rows + j) * a.Cout + co] = j < Cin * 9 ? acc[j < 72 ? j : 0] : bsum;
+  }
+  __syncthreads();
+  for (int i = tid; i < rows * a.Cout; i += 256) {
+    float v = 0.f;
+    for (int q = 0; q < lanes; ++q) v += red[(size_t)q * rows * a.Cout + i];
+    out[i] = v;
   }
 }
 __global__ void init_bwd_weight_reduce_kernel(const float* partial, float* dw, float* dbias, int nparts, int Cin, int Cout) {
@@ -879,7 +896,15 @@ hipError_t launch_init_bwd_weight(int dtype, const InitBwdArgs& a, hipStream_t s
   const int Cin = a.c0 + a.c1;
   if (a.Cout > 256 || 256 % a.Cout || Cin > 8 || a.H % kHeadRows) return hipErrorInvalidValue;
   dim3 grid(a.H / kHeadRows, a.B);
-  const size_t lds = 256 * sizeof(float);
+  const size_t lds = (size_t)256 * (Cin * 9 + 1) * sizeof(float);  // [256 / Cout lanes][rows][Cout]
+  if (lds > 64 * 1024) return hipErrorInvalidValue;
+  if (lds > 48 * 1024) {
+    hipError_t e = hipSuccess;
+    if (dtype == 0) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&init_bwd_weight_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    else if (dtype == 1) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&init_bwd_weight_kernel<half_t>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    else e = hipFuncSetAttribute(reinterpret_cast<const void*>(&init_bwd_weight_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+  }
   switch (dtype) {
     case 0: hipLaunchKernelGGL(init_bwd_weight_kernel<float>, grid, dim3(256), lds, s, a); break;
     case 1: hipLaunchKernelGGL(init_bwd_weight_kernel<half_t>, grid, dim3(256), lds, s, a); break;
@@ -887,8 +912,13 @@ hipError_t launch_init_bwd_weight(int dtype, const InitBwdArgs& a, hipStream_t s
     default: return hipErrorInvalidValue;
   }
   const int n = (Cin * 9 + 1) * a.Cout;
+  int nparts = a.B * (a.H / kHeadRows);
+  if (nparts > kPartGroups) {
+    hipLaunchKernelGGL(partial_groups_kernel, dim3((n + 255) / 256, kPartGroups), dim3(256), 0, s, a.partial, (int64_t)n, nparts);
+    nparts = kPartGroups;
+  }
   hipLaunchKernelGGL(init_bwd_weight_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, s, a.partial, a.dw, a.dbias,
-                     a.B * (a.H / kHeadRows), Cin, a.Cout);
+                     nparts, Cin, a.Cout);
   return hipGetLastError();
 }
 

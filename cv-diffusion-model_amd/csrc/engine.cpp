@@ -7,6 +7,7 @@
 // sequence with launches disabled to obtain the high-water mark.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -989,6 +990,7 @@ struct Back {
     {
       const int nt = P / 64;
       const size_t slab = alloc((size_t)B * nt * 2 * hid * 4);
+      const size_t sescr = alloc((size_t)std::max(linear_dx_chunks(hid) * w.sq, linear_dx_chunks(w.sq) * hid) * B * 4);
       if (!dry) {
         BwdMaskArgs m{};
         m.g = p(da3); m.x0 = p(r.h2); m.c0 = hid; m.act = ACT_NONE; m.slab = p<float>(slab); m.M = M; m.C = hid; m.P = P;
@@ -996,13 +998,13 @@ struct Back {
         chk(launch_slab_reduce(p<float>(slab) + hid, p<float>(dgate), B, nt, 2, 1, hid, s));
         chk(launch_sigmoid_bwd(p<float>(dgate), p<float>(r.gate), p<float>(dpre2), (int64_t)B * hid, s));
         chk(launch_linear_dw(p<float>(dpre2), hid, p<float>(r.sehid), gp(pf + 8), gp(pf + 9), B, hid, w.sq, s));
-        chk(launch_linear_dx(dt, p<float>(dpre2), hid, wptr(w.se_w2), p<float>(dr), B, hid, w.sq, s));
+        chk(launch_linear_dx(dt, p<float>(dpre2), hid, wptr(w.se_w2), p<float>(dr), B, hid, w.sq, s, p<float>(sescr)));
         chk(launch_relu6_bwd(p<float>(dr), p<float>(r.sehid), p<float>(dr), (int64_t)B * w.sq, s));
         chk(launch_linear_dw(p<float>(dr), w.sq, p<float>(r.semean), gp(pf + 6), gp(pf + 7), B, w.sq, hid, s));
-        chk(launch_linear_dx(dt, p<float>(dr), w.sq, wptr(w.se_w1), p<float>(dmean), B, w.sq, hid, s));
+        chk(launch_linear_dx(dt, p<float>(dr), w.sq, wptr(w.se_w1), p<float>(dmean), B, w.sq, hid, s, p<float>(sescr)));
         chk(launch_scale_rows(p<float>(dmean), p<float>(dmean), (int64_t)B * hid, 1.f / (float)P, s));
       }
-      ar->free(slab);
+      ar->free(slab); ar->free(sescr);
     }
     // depthwise: input gradient (same kernel, flipped taps, prologue dh2 = da3*gate + dmean/P) and weight gradient
     const size_t da2 = alloc((size_t)M * hid * es());
