@@ -835,6 +835,7 @@ hipError_t launch_final_bwd_weight(int dtype, const FinalBwdArgs& a, hipStream_t
   return hipGetLastError();
 }
 
+constexpr int kInitPass = 16;  // rows per LDS pass of the block reduction (16 KB)
 // ---- input conv weight gradient: dW[co][ci][tap] = sum_{b,p} g[p][co] * x[ci][p + tap - 1]  (x fp32 NCHW planes)
 template <typename T>
 __global__ void __launch_bounds__(256) init_bwd_weight_kernel(const InitBwdArgs a) {
@@ -867,19 +868,22 @@ __global__ void __launch_bounds__(256) init_bwd_weight_kernel(const InitBwdArgs 
       }
     }
   }
-  // all (row, channel) sums of the block through LDS at once: red[lane][row][co]
+  // the (row, channel) sums of the block go through LDS in passes of kInitPass rows: red[lane][row][co]
   const int rows = Cin * 9 + 1;
   float* out = a.partial + ((size_t)b * gridDim.x + blockIdx.x) * rows * a.Cout;
+  for (int j0 = 0; j0 < rows; j0 += kInitPass) {
+    const int nr = min(kInitPass, rows - j0);
+    __syncthreads();
 #pragma unroll
-  for (int j = 0; j < 73; ++j) {
-    if (j >= rows) break;
-    red[((size_t)pl * rows + j) * a.Cout + co] = j < Cin * 9 ? acc[j < 72 ? j : 0] : bsum;
-  }
-  __syncthreads();
-  for (int i = tid; i < rows * a.Cout; i += 256) {
-    float v = 0.f;
-    for (int q = 0; q < lanes; ++q) v += red[(size_t)q * rows * a.Cout + i];
-    out[i] = v;
+    for (int j = 0; j < 73; ++j) {
+      if (j >= j0 && j < j0 + nr) red[((size_t)pl * kInitPass + (j - j0)) * a.Cout + co] = j < Cin * 9 ? acc[j < 72 ? j : 0] : bsum;
+    }
+    __syncthreads();
+    for (int i = tid; i < nr * a.Cout; i += 256) {
+      float v = 0.f;
+      for (int q = 0; q < lanes; ++q) v += red[(size_t)q * kInitPass * a.Cout + i];
+      out[(size_t)j0 * a.Cout + i] = v;
+    }
   }
 }
 __global__ void init_bwd_weight_reduce_kernel(const float* partial, float* dw, float* dbias, int nparts, int Cin, int Cout) {
@@ -896,15 +900,7 @@ hipError_t launch_init_bwd_weight(int dtype, const InitBwdArgs& a, hipStream_t s
   const int Cin = a.c0 + a.c1;
   if (a.Cout > 256 || 256 % a.Cout || Cin > 8 || a.H % kHeadRows) return hipErrorInvalidValue;
   dim3 grid(a.H / kHeadRows, a.B);
-  const size_t lds = (size_t)256 * (Cin * 9 + 1) * sizeof(float);  // [256 / Cout lanes][rows][Cout]
-  if (lds > 64 * 1024) return hipErrorInvalidValue;
-  if (lds > 48 * 1024) {
-    hipError_t e = hipSuccess;
-    if (dtype == 0) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&init_bwd_weight_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    else if (dtype == 1) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&init_bwd_weight_kernel<half_t>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    else e = hipFuncSetAttribute(reinterpret_cast<const void*>(&init_bwd_weight_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-  }
+  const size_t lds = (size_t)256 * kInitPass * sizeof(float);  // [256 / Cout lanes][kInitPass rows][Cout]
   switch (dtype) {
     case 0: hipLaunchKernelGGL(init_bwd_weight_kernel<float>, grid, dim3(256), lds, s, a); break;
     case 1: hipLaunchKernelGGL(init_bwd_weight_kernel<half_t>, grid, dim3(256), lds, s, a); break;

@@ -91,8 +91,8 @@ SHAPES = [  # (name, kind, P, segs, N)   small@256, B=32
 if __name__ == "__main__":
     B = 32
     if "gemm" in sys.argv[1:]:
-        knobs = [("v1", 0), ("v2", 1), ("v1b", 0), ("v2b", 1)]
-        print(f"{'shape':28s} " + " ".join(f"{k:>16s}" for k, _ in knobs))
+        knobs = [("v1", 0), ("v1b", 0)]
+        print(f"{'shape':28s} " + " ".join(f"{k:>26s}" for k, _ in knobs))
         tot = {k: 0.0 for k, _ in knobs}
         for name, kind, P, segs, n in SHAPES:
             row = []
@@ -100,8 +100,8 @@ if __name__ == "__main__":
                 L.llie_tune(b"gemm_v2", v)
                 us, gbs, tf = gemm(kind, B * P, segs, n, P)
                 tot[k] += us
-                row.append(f"{us:8.1f}us {tf:5.0f}TF")
-            print(f"{name:28s} " + " ".join(f"{r:>16s}" for r in row), flush=True)
+                row.append(f"{us:8.1f}us {tf:4.0f}TF {gbs:5.0f}GB/s")
+            print(f"{name:28s} " + " ".join(f"{r:>26s}" for r in row), flush=True)
         print("sum(us):", {k: round(v, 1) for k, v in tot.items()})
         L.llie_tune(b"gemm_v2", 0)
     if "dw" in sys.argv[1:]:
