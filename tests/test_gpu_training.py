@@ -114,12 +114,16 @@ def _ref_unet_grads(sd, spec, low, normal, t, noise, loss="mse"):
     return lv.detach(), pred.detach(), {k: v.grad for k, v in sdg.items()}
 
 
-def _small(size, dev):
-    spec = oracle.make_spec("small", size)
+def _model(variant, size, dev):
+    spec = oracle.make_spec(variant, size)
     sd = oracle.synth_state_dict(oracle.param_shapes(spec))
-    m = M.LowLightDiffusion(unet_variant="small", image_size=size, num_inference_steps=4)
+    m = M.LowLightDiffusion(unet_variant=variant, image_size=size, num_inference_steps=4)
     m.load_state_dict(sd)
     return m.to(dev).train(), sd, spec
+
+
+def _small(size, dev):
+    return _model("small", size, dev)
 
 
 @pytest.mark.parametrize("cd,max_l2,min_cos", [(None, 5e-3, 0.9999), ("bf16", 0.25, 0.98), ("fp16", 0.25, 0.98)])
@@ -273,3 +277,27 @@ def test_training_step_vs_reference_golden(golden, dev):
             ref = torch.from_numpy(g[name])
             assert rel_err(grads[name[5:]].grad, ref) < 5e-3, name
             assert cosine(grads[name[5:]].grad, ref) > 0.9999, name
+
+
+def test_unet_backward_large64_and_small128(dev):
+    """Other topologies: large (C0=64, 3 blocks per level, T=256, 8 heads) at 64x64, and small at 128x128
+    (attention only at the two coarsest levels); B=1, fp32 engine vs CPU autograd."""
+    for variant, size in (("large", 64), ("small", 128)):
+        m, sd, spec = _model(variant, size, dev)
+        g = torch.Generator().manual_seed(7)
+        low = torch.rand(1, 3, size, size, generator=g) * 2 - 1
+        normal = torch.rand(1, 3, size, size, generator=g) * 2 - 1
+        noise = torch.randn(1, 3, size, size, generator=g)
+        t = torch.tensor([321])
+        loss_ref, pred_ref, gref = _ref_unet_grads(sd, spec, low, normal, t, noise, loss="l1")
+        out = m(low.to(dev), normal.to(dev), timesteps=t.to(dev), noise=noise.to(dev))
+        loss = torch.nn.functional.l1_loss(out["noise_pred"], out["noise"])
+        loss.backward()
+        assert abs(loss.item() - loss_ref.item()) < 1e-5 * max(1.0, abs(loss_ref.item()))
+        bad = {}
+        for k, p in m.named_parameters():
+            a, b = p.grad.double().cpu(), gref[k].double()
+            l2, cs = ((a - b).norm() / b.norm().clamp_min(1e-30)).item(), cosine(a, b)
+            if not (l2 < 2e-2 and cs > 0.9995):
+                bad[k] = (l2, cs)
+        assert not bad, f"{variant}@{size}: {len(bad)} tensors off: {dict(list(bad.items())[:8])}"
