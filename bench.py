@@ -81,6 +81,59 @@ def cpu_baseline(variant: str, size: int, steps: int, state_dict, budget_s: floa
             "sample": f"enhance(B=1, {variant}@{size}, {steps} steps, fp32), {note}, torch CPU threads={ncores}"}
 
 
+def train_bench(args, M, dev, rank: int, world: int) -> None:
+    """One step = the reference trainer's inner loop (trainer.py:281-338) on `--batch` images per GPU: q-sample,
+    engine forward with kept activations, MSE, engine backward, one flat gradient all-reduce over the ranks,
+    clip_grad_norm_(1.0), AdamW, EMA(0.9999).  Synthetic image pairs resident in HBM."""
+    model = M.LowLightDiffusion(unet_variant=args.variant, image_size=args.image_size, compute_dtype=args.dtype).to(dev).train()
+    B, S = args.batch, args.image_size
+    g = torch.Generator().manual_seed(1234 + rank)
+    low = (torch.rand(B, 3, S, S, generator=g) * 2 - 1).to(dev)
+    normal = (torch.rand(B, 3, S, S, generator=g) * 2 - 1).to(dev)
+    params = list(model.parameters())
+    opt = torch.optim.AdamW(params, lr=1e-4, weight_decay=0.01, fused=True)
+    ema = [p.detach().clone() for p in params]
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        loss = model.compute_loss(low, normal, loss_type="mse")
+        loss.backward()
+        M.all_reduce_gradients(params)
+        torch.nn.utils.clip_grad_norm_(params, 1.0)
+        opt.step()
+        torch._foreach_mul_(ema, 0.9999)
+        torch._foreach_add_(ema, [p.detach() for p in params], alpha=1 - 0.9999)
+        return loss
+
+    log(f"training model built on {dev}; warm-up x{args.warmup}")
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    if rank == 0:
+        print(json.dumps({
+            "metric": "training images/sec (whole node), 256x256 'small' (BASELINE config 5)",
+            "value": round(world * B * args.steps / elapsed, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic (random-init weights, uniform image pairs)",
+            "config": {"workload": f"variant={args.variant}, {S}x{S}, batch={B}/GPU, training step (MSE, AdamW, clip 1.0, EMA), "
+                                   f"{args.dtype}, {world}xMI355X", "global_batch": world * B,
+                       "parallelism": "single GPU" if world == 1 else f"dp{world} (one flat gradient all-reduce)"},
+            "final_loss": round(float(loss.item()), 5)}), flush=True)
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -93,6 +146,9 @@ def main() -> None:
     ap.add_argument("--dtype", default="fp16", choices=["fp32", "fp16", "bf16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--train", action="store_true",
+                    help="time the training step instead (BASELINE config 5; not the headline line): compute_loss -> "
+                         "backward -> gradient all-reduce -> clip -> AdamW -> EMA, as src/training/trainer.py:281-338")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -109,6 +165,11 @@ def main() -> None:
 
     M = importlib.import_module("cv-diffusion-model_amd")
     torch.manual_seed(0)
+    if args.train:
+        train_bench(args, M, dev, rank, world)
+        if world > 1:
+            dist.destroy_process_group()
+        return
     model = M.LowLightDiffusion(unet_variant=args.variant, image_size=args.image_size,
                                 num_inference_steps=args.lcm_steps, compute_dtype=args.dtype).to(dev).eval()
     B, S = args.batch, args.image_size

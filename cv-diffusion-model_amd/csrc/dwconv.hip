@@ -34,7 +34,7 @@ __device__ __forceinline__ void fma_mix_f16(float& acc, uint32_t w2, uint32_t f2
 constexpr int kDwPF = 4;  // rows of global loads kept in flight per thread
 
 template <typename T, int TX, int PFV>
-__global__ void __launch_bounds__(8 * TX) dwconv3x3_kernel(const DwArgs a, const int TYL, const int dbg) {
+__global__ void __launch_bounds__(8 * TX) dwconv3x3_kernel(const DwArgs a, const int TYL, const int dbg, const int swap) {
   constexpr int NT = 8 * TX;
   constexpr int VEC = Elem<T>::VEC;
   constexpr int CC = 8 * VEC;  // channels per workgroup
@@ -46,9 +46,12 @@ __global__ void __launch_bounds__(8 * TX) dwconv3x3_kernel(const DwArgs a, const
 
   const int tid = threadIdx.x, cl = tid & 7, xl = tid >> 3;
   const int tiles_x = a.W / TX;
-  const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
+  // grid: x = channel chunk (fastest, so the workgroups that share a strip's DRAM pages are dispatched together when
+  // g_dw_swap is set), y = strip; or x = strip, y = chunk
+  const int tile_id = swap ? blockIdx.y : blockIdx.x, chunk_id = swap ? blockIdx.x : blockIdx.y;
+  const int tx = tile_id % tiles_x, ty = tile_id / tiles_x;
   const int x0 = tx * TX, y0 = ty * TYL;
-  const int c0 = blockIdx.y * CC + cl * VEC;
+  const int c0 = chunk_id * CC + cl * VEC;
   const int b = blockIdx.z;
   const T* in = reinterpret_cast<const T*>(a.in) + (size_t)b * a.H * a.W * a.C + c0;
   T* out = reinterpret_cast<T*>(a.out) + (size_t)b * a.H * a.W * a.C + c0;
@@ -165,11 +168,13 @@ __global__ void __launch_bounds__(8 * TX) dwconv3x3_kernel(const DwArgs a, const
   if (a.pool) {
     __syncthreads();
     const int ntiles = tiles_x * (a.H / kPoolSegRows);
-    pool_segments_store<CC, NT>(red, TYL / kPoolSegRows, tid, a.pool + (size_t)b * ntiles * a.C + blockIdx.y * CC, a.C,
+    pool_segments_store<CC, NT>(red, TYL / kPoolSegRows, tid, a.pool + (size_t)b * ntiles * a.C + chunk_id * CC, a.C,
                                 ty * (TYL / kPoolSegRows), tiles_x, tx);
   }
 }
 
+static int g_dw_swap = 0;
+void dwconv_swap(int v) { g_dw_swap = v; }
 static int g_dw_dbg = 0;
 void dwconv_debug(int v) { g_dw_dbg = v; }  // bits 0-1: timing ablations
 static int dw_tx(int W) { return (W % 32 == 0) ? 32 : ((W % 16 == 0) ? 16 : 8); }
@@ -191,13 +196,14 @@ static hipError_t launch_dw_t(const DwArgs& a, hipStream_t s) {
   if (a.C % CC || a.H % 8 || a.W % 8) return hipErrorInvalidValue;
   const int tx = dw_tx(a.W), tyl = dw_pick_tyl(a.B, a.H, a.W, a.C / CC);
   dim3 grid((a.W / tx) * (a.H / tyl), a.C / CC, a.B);
+  if (g_dw_swap) grid = dim3(a.C / CC, (a.W / tx) * (a.H / tyl), a.B);
   static const std::string names[3] = {std::string("dwconv3x3_kernel<") + TypeName<T>::value + ", 32, 4>",
                                        std::string("dwconv3x3_kernel<") + TypeName<T>::value + ", 16, 4>",
                                        std::string("dwconv3x3_kernel<") + TypeName<T>::value + ", 8, 4>"};
   note_kernel(names[tx == 32 ? 0 : (tx == 16 ? 1 : 2)].c_str());
-  if (tx == 32) hipLaunchKernelGGL((dwconv3x3_kernel<T, 32, kDwPF>), grid, dim3(256), 0, s, a, tyl, g_dw_dbg & 3);
-  else if (tx == 16) hipLaunchKernelGGL((dwconv3x3_kernel<T, 16, kDwPF>), grid, dim3(128), 0, s, a, tyl, g_dw_dbg & 3);
-  else hipLaunchKernelGGL((dwconv3x3_kernel<T, 8, kDwPF>), grid, dim3(64), 0, s, a, tyl, g_dw_dbg & 3);
+  if (tx == 32) hipLaunchKernelGGL((dwconv3x3_kernel<T, 32, kDwPF>), grid, dim3(256), 0, s, a, tyl, g_dw_dbg & 3, g_dw_swap);
+  else if (tx == 16) hipLaunchKernelGGL((dwconv3x3_kernel<T, 16, kDwPF>), grid, dim3(128), 0, s, a, tyl, g_dw_dbg & 3, g_dw_swap);
+  else hipLaunchKernelGGL((dwconv3x3_kernel<T, 8, kDwPF>), grid, dim3(64), 0, s, a, tyl, g_dw_dbg & 3, g_dw_swap);
   return hipGetLastError();
 }
 

@@ -1763,6 +1763,7 @@ int llie_tune(const char* knob, int value) {
   if (!strcmp(knob, "dwx")) { g_use_dwx = value != 0; return LLIE_OK; }
   if (!strcmp(knob, "gemm_ablate")) { pw_gemm_debug(value); return LLIE_OK; }
   if (!strcmp(knob, "dw_ablate")) { dwconv_debug(value); return LLIE_OK; }
+  if (!strcmp(knob, "dw_swap")) { dwconv_swap(value); return LLIE_OK; }
   return LLIE_ERR_ARG;
 }
 

@@ -106,6 +106,7 @@ bool dwx_supported(int dtype, int Cin, int Chid, int H, int W);
 hipError_t launch_dwx(int dtype, const DwxArgs& a, hipStream_t s);
 int dwconv_ntiles(int H, int W);  // pool slab entries per image: (H/8 row segments) x (W / strip width)
 int dw_pick_tyl(int B, int H, int W, int chunks);
+void dwconv_swap(int v);   // 1: channel chunk is the fastest grid index
 void dwconv_debug(int v);  // timing ablations (bit 0: no MACs, bit 1: no activation); results are wrong when set
 
 // Squeeze-and-Excitation MLP (efficient_unet.py:96-100) in two launches.

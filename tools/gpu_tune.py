@@ -108,12 +108,12 @@ if __name__ == "__main__":
         for rep in range(2):
             for H, Cc in [(256, 128), (256, 384), (128, 768), (64, 1536)]:
                 row = []
-                for mode in (0, 1, 2, 3):
-                    L.llie_tune(b"dw_ablate", mode)
+                for mode in (0, 1):
+                    L.llie_tune(b"dw_swap", mode)
                     us, gbs = dw(B, H, Cc)
-                    row.append(f"m{mode}: {us:7.1f}us {gbs:5.0f}GB/s")
+                    row.append(f"swap{mode}: {us:7.1f}us {gbs:5.0f}GB/s")
                 print(f"dw {H}x{H} C={Cc}: " + " | ".join(row), flush=True)
-        L.llie_tune(b"dw_ablate", 0)
+        L.llie_tune(b"dw_swap", 0)
 
 
 def chain(B, Bc, P, H, cin, hid, cout, iters=5):
