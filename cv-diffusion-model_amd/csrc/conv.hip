@@ -400,7 +400,7 @@ __global__ void __launch_bounds__(WM* WN * 64) conv3x3_kernel(const Conv3Args a)
 
   extern __shared__ __align__(16) unsigned char smem[];
   T* sP = reinterpret_cast<T*>(smem);
-  T* sB = sP + PH * PW * PITCH;
+  T* sB = sP + PH * PW * PITCH;  // [2][BN][PITCH]
   float* sC = reinterpret_cast<float*>(smem);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -444,38 +444,102 @@ __global__ void __launch_bounds__(WM* WN * 64) conv3x3_kernel(const Conv3Args a)
       }
     }
   };
-  auto stage_w = [&]() {
+  auto stage_w = [&](int buf) {  // two W tiles in LDS: tap t computes from buffer t & 1 while t + 1 is being written
 #pragma unroll
     for (int i = 0; i < B_PER; ++i) {
       const int idx = tid + i * NT;
-      if (B_VECS % NT == 0 || idx < B_VECS) st_vec<T>(sB + (idx / VPR) * PITCH + kv, rb[i]);
+      if (B_VECS % NT == 0 || idx < B_VECS) st_vec<T>(sB + buf * (BN * PITCH) + (idx / VPR) * PITCH + kv, rb[i]);
     }
   };
 
+  // Input patch of one 32-channel chunk: the global loads are issued one chunk ahead (issue_patch keeps the raw
+  // vectors in registers while the nine taps of the current chunk run) and turned into the LDS patch afterwards
+  // (commit_patch: bounds -> zeros, MODE 1 interpolates its four neighbours).
+  constexpr int P_ITEMS = (PH * PW * VPR + NT - 1) / NT, P_LOADS = MODE == 1 ? 4 : 1;
+  vec_t praw[P_ITEMS][P_LOADS];
+  struct Src { bool ok; int o00, o01, o10, o11; float ly1, lx1; };
+  auto patch_src = [&](int i) {
+    Src r{false, 0, 0, 0, 0, 0.f, 0.f};
+    if (i >= PH * PW * VPR) return r;
+    const int pix = i / VPR;
+    const int ppy = pix / PW, ppx = pix % PW;
+    if (MODE == 0 || MODE == 2) {
+      const int gy = (MODE == 0 ? 2 * oy0 : oy0) - 1 + ppy, gx = (MODE == 0 ? 2 * ox0 : ox0) - 1 + ppx;
+      r.ok = gy >= 0 && gy < a.Hi && gx >= 0 && gx < a.Wi;
+      r.o00 = (gy * a.Wi + gx) * a.Cin;
+    } else {
+      const int uy = oy0 - 1 + ppy, ux = ox0 - 1 + ppx;  // coordinates in the upsampled image
+      r.ok = uy >= 0 && uy < Ho && ux >= 0 && ux < Wo;
+      float sy = ((float)uy + 0.5f) * 0.5f - 0.5f, sx = ((float)ux + 0.5f) * 0.5f - 0.5f;
+      sy = sy < 0.f ? 0.f : sy;
+      sx = sx < 0.f ? 0.f : sx;
+      const int iy0 = (int)sy, ix0 = (int)sx;
+      const int iy1 = min(iy0 + 1, a.Hi - 1), ix1 = min(ix0 + 1, a.Wi - 1);
+      r.ly1 = sy - (float)iy0; r.lx1 = sx - (float)ix0;
+      r.o00 = (iy0 * a.Wi + ix0) * a.Cin; r.o01 = (iy0 * a.Wi + ix1) * a.Cin;
+      r.o10 = (iy1 * a.Wi + ix0) * a.Cin; r.o11 = (iy1 * a.Wi + ix1) * a.Cin;
+    }
+    return r;
+  };
+  auto issue_item = [&](int it, int c0) {
+    {
+      const Src r = patch_src(tid + it * NT);
+      if (r.ok) {
+        const T* base = in + c0 + kv;
+        praw[it][0] = ld_vec<T>(base + r.o00);
+        if (MODE == 1) {
+          praw[it][P_LOADS > 1 ? 1 : 0] = ld_vec<T>(base + r.o01);
+          praw[it][P_LOADS > 2 ? 2 : 0] = ld_vec<T>(base + r.o10);
+          praw[it][P_LOADS > 3 ? 3 : 0] = ld_vec<T>(base + r.o11);
+        }
+      }
+    }
+  };
+  auto commit_item = [&](int it) {
+    {
+      const int i = tid + it * NT;
+      if (i >= PH * PW * VPR) return;
+      const Src r = patch_src(i);
+      vec_t v;
+      if (!r.ok) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) v[e] = (T)0.f;
+      } else if (MODE == 1) {
+        const float ly0 = 1.f - r.ly1, lx0 = 1.f - r.lx1;
+        float f00[VEC], f01[VEC], f10[VEC], f11[VEC], f[VEC];
+        vec_to_f32<T>(praw[it][0], f00);
+        vec_to_f32<T>(praw[it][P_LOADS > 1 ? 1 : 0], f01);
+        vec_to_f32<T>(praw[it][P_LOADS > 2 ? 2 : 0], f10);
+        vec_to_f32<T>(praw[it][P_LOADS > 3 ? 3 : 0], f11);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e)
+          f[e] = ly0 * (lx0 * f00[e] + r.lx1 * f01[e]) + r.ly1 * (lx0 * f10[e] + r.lx1 * f11[e]);
+        v = f32_to_vec<T>(f);
+      } else {
+        v = praw[it][0];
+      }
+      st_vec<T>(sP + (i / VPR) * PITCH + kv, v);
+    }
+  };
+
+  // measured: the look-ahead pays everywhere except the 64-channel upsampling conv (4 x 3 raw vectors per thread
+  // cost it an occupancy step: 294 -> 365 us), which keeps load-then-use
+  constexpr bool PREF = !(MODE == 1 && BN == 64);
+  auto issue_patch = [&](int c0) {
+#pragma unroll
+    for (int it = 0; it < P_ITEMS; ++it) issue_item(it, c0);
+  };
+  if (PREF) issue_patch(0);
   for (int c0 = 0; c0 < a.Cin; c0 += 32) {
     prefetch_w(0, c0);
-    // ---- stage the input patch for this channel chunk
-    for (int i = tid; i < PH * PW * VPR; i += NT) {
-      const int pix = i / VPR;
-      const int ppy = pix / PW, ppx = pix % PW;
-      vec_t v;
-      if (MODE == 0) {
-        const int gy = 2 * oy0 - 1 + ppy, gx = 2 * ox0 - 1 + ppx;
-        if (gy >= 0 && gy < a.Hi && gx >= 0 && gx < a.Wi) {
-          v = ld_vec<T>(in + ((size_t)gy * a.Wi + gx) * a.Cin + c0 + kv);
-        } else {
+    if constexpr (PREF) {  // this chunk's patch: its loads were issued during the previous chunk's taps
 #pragma unroll
-          for (int e = 0; e < VEC; ++e) v[e] = (T)0.f;
-        }
-      } else if (MODE == 2) {
-        const int gy = oy0 - 1 + ppy, gx = ox0 - 1 + ppx;
-        if (gy >= 0 && gy < a.Hi && gx >= 0 && gx < a.Wi) {
-          v = ld_vec<T>(in + ((size_t)gy * a.Wi + gx) * a.Cin + c0 + kv);
-        } else {
-#pragma unroll
-          for (int e = 0; e < VEC; ++e) v[e] = (T)0.f;
-        }
-      } else {
+      for (int it = 0; it < P_ITEMS; ++it) commit_item(it);
+    } else {  // load-then-use, one item at a time (lowest register footprint); MODE 1 only
+      for (int i = tid; i < PH * PW * VPR; i += NT) {
+        const int pix = i / VPR;
+        const int ppy = pix / PW, ppx = pix % PW;
+        vec_t v;
         const int uy = oy0 - 1 + ppy, ux = ox0 - 1 + ppx;  // coordinates in the upsampled image
         if (uy >= 0 && uy < Ho && ux >= 0 && ux < Wo) {
           float sy = ((float)uy + 0.5f) * 0.5f - 0.5f, sx = ((float)ux + 0.5f) * 0.5f - 0.5f;
@@ -498,13 +562,14 @@ __global__ void __launch_bounds__(WM* WN * 64) conv3x3_kernel(const Conv3Args a)
 #pragma unroll
           for (int e = 0; e < VEC; ++e) v[e] = (T)0.f;
         }
+        st_vec<T>(sP + pix * PITCH + kv, v);
       }
-      st_vec<T>(sP + pix * PITCH + kv, v);
     }
+    stage_w(0);
+    prefetch_w(1, c0);
+    __syncthreads();  // patch and W tile of tap 0 visible
+    if (PREF && c0 + 32 < a.Cin) issue_patch(c0 + 32);
     for (int tap = 0; tap < 9; ++tap) {
-      stage_w();
-      __syncthreads();  // patch (first tap) and W tile visible
-      if (tap + 1 < 9) prefetch_w(tap + 1, c0);
       const int toff = ((tap / 3) * PW + (tap % 3)) * PITCH;
       T fa[MI][16], fb[NI][16];
 #pragma unroll
@@ -515,7 +580,7 @@ __global__ void __launch_bounds__(WM* WN * 64) conv3x3_kernel(const Conv3Args a)
       }
 #pragma unroll
       for (int j = 0; j < NI; ++j) {
-        const T* p = sB + ((wn * NI + j) * 32 + (lane & 31)) * PITCH + (lane >> 5) * 16;
+        const T* p = sB + (tap & 1) * (BN * PITCH) + ((wn * NI + j) * 32 + (lane & 31)) * PITCH + (lane >> 5) * 16;
 #pragma unroll
         for (int q = 0; q < 16 / VEC; ++q) *reinterpret_cast<vec_t*>(&fb[j][q * VEC]) = *reinterpret_cast<const vec_t*>(p + q * VEC);
       }
@@ -523,7 +588,11 @@ __global__ void __launch_bounds__(WM* WN * 64) conv3x3_kernel(const Conv3Args a)
       for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < NI; ++j) Mfma<T>::chunk(fa[i], fb[j], acc[i][j]);
-      __syncthreads();  // everyone done with sB (and, after tap 8, with the patch)
+      if (tap + 1 < 9) {
+        stage_w((tap + 1) & 1);  // its last readers finished before the previous barrier
+        if (tap + 2 < 9) prefetch_w(tap + 2, c0);
+      }
+      __syncthreads();  // next W tile visible; everyone done with this one (and, after tap 8, with the patch)
     }
   }
 
@@ -604,7 +673,7 @@ template <typename T, int MODE, int TW, int BN, int WM, int WN>
 static hipError_t launch_conv_cfg(const Conv3Args& a, hipStream_t s) {
   constexpr int NT = WM * WN * 64, BM = 8 * TW, PITCH = TilePitch<T>::value;
   constexpr int PH = MODE == 0 ? 17 : 10, PW = MODE == 0 ? 2 * TW + 1 : TW + 2;
-  constexpr size_t tiles = (size_t)(PH * PW + BN) * PITCH * sizeof(T);
+  constexpr size_t tiles = (size_t)(PH * PW + 2 * BN) * PITCH * sizeof(T);
   constexpr size_t ctile = (size_t)(WM * 32) * (BN + 4) * 4 + (size_t)(NT / 64) * 2 * BN * 4;
   constexpr size_t lds = tiles > ctile ? tiles : ctile;
   static bool attr_done = false;
