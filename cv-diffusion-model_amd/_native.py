@@ -25,7 +25,7 @@ EXPORTS = [
     "llie_profile_begin", "llie_profile_end", "llie_enhance_workspace_bytes",
     "llie_preprocess_u8", "llie_postprocess_u8", "llie_profile_report", "llie_pw_gemm", "llie_pw_gemm_tile_rows", "llie_dwconv3x3", "llie_dwconv3x3_tiles", "llie_tune",
     "llie_grad_numel", "llie_param_grad_offset", "llie_train_workspace_bytes", "llie_unet_train_forward",
-    "llie_unet_backward", "llie_module_backward",
+    "llie_unet_backward", "llie_module_backward", "llie_load_all",
 ]
 K_GEMM, K_DW, K_CONV3, K_SE = 1, 2, 4, 8
 
@@ -80,6 +80,7 @@ def lib() -> C.CDLL:
     L.llie_param_info.argtypes = [vp, ci, C.c_char_p, C.c_size_t, C.POINTER(i64), C.POINTER(ci), C.POINTER(i64)]
     L.llie_load_param.argtypes = [vp, C.c_char_p, vp, i64, vp]
     L.llie_params_loaded.argtypes = [vp]
+    L.llie_load_all.argtypes = [vp, C.POINTER(vp), ci, vp]
     L.llie_workspace_bytes.argtypes = [vp, ci, ci, ci]
     L.llie_workspace_bytes.restype = i64
     L.llie_enhance_workspace_bytes.argtypes = [vp, ci, ci]
@@ -177,6 +178,11 @@ class Handle:
 
     def load_param(self, key: str, tensor, stream: int) -> None:
         check(self._L.llie_load_param(self.h, key.encode(), tensor.data_ptr(), tensor.numel(), stream), "load_state_dict")
+
+    def load_all(self, tensors, stream: int) -> None:
+        """Reload every parameter (llie_param_info order) from fp32 contiguous device tensors in one call."""
+        arr = (C.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+        check(self._L.llie_load_all(self.h, arr, len(tensors), stream), "load_state_dict")
 
     def params_loaded(self) -> bool:
         return bool(self._L.llie_params_loaded(self.h))

@@ -175,6 +175,9 @@ struct llie_ctx {
   size_t t_w1 = 0, t_b1 = 0, t_w3 = 0, t_b3 = 0, freqs = 0, film_w = 0, film_b = 0;
   int film_rows = 0;
   int64_t grad_numel = 0;
+  // batched reload (llie_load_all): device descriptor table + the host pointers it was built for
+  LoadDesc* load_descs = nullptr;
+  std::vector<const float*> load_srcs;
   Tape tape;           // last training forward (llie_unet_train_forward), read by llie_unet_backward
   Arena* train_arena = nullptr;  // arena state after that forward; the backward pass continues in it
   size_t init_wp = 0, fin_wp = 0;  // MFMA-packed init / final conv weights (2-byte compute dtypes)
@@ -1354,6 +1357,7 @@ void llie_destroy(llie_ctx* c) {
   for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
   if (c->blob) (void)hipFree(c->blob);
   delete c->train_arena;
+  if (c->load_descs) (void)hipFree(c->load_descs);
   delete c;
 }
 
@@ -1407,6 +1411,54 @@ int llie_load_param(llie_ctx* c, const char* key, const float* src, int64_t nume
   }
   if (e != hipSuccess) { set_err("repack of '%s' failed: %s", key, hipGetErrorString(e)); return (int)e; }
   p.loaded = true;
+  return LLIE_OK;
+}
+
+// Reload every parameter from `srcs[i]` (device fp32, llie_param_info order) -- what an optimiser step needs.  All
+// plain / matrix / 3x3 / depthwise tensors go through one kernel driven by a descriptor table that is rebuilt only
+// when a source pointer changes; the input and output convolutions keep their own repack kernels.
+int llie_load_all(llie_ctx* c, const float* const* srcs, int n, llie_stream stream) {
+  if (!c || !srcs || n != (int)c->params.size()) return LLIE_ERR_ARG;
+  if (!c->blob) { set_err("no HIP device"); return LLIE_ERR_NO_DEVICE; }
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  std::vector<int> batched;
+  for (int i = 0; i < n; ++i) {
+    if (!srcs[i]) return LLIE_ERR_ARG;
+    const PKind k = c->params[i].kind;
+    if (k == PK_F32 || k == PK_MAT || k == PK_CONV3 || k == PK_DW) batched.push_back(i);
+  }
+  bool rebuild = !c->load_descs || (int)c->load_srcs.size() != n;
+  for (int i = 0; !rebuild && i < n; ++i) rebuild = c->load_srcs[i] != srcs[i];
+  if (rebuild) {
+    std::vector<LoadDesc> d;
+    for (int i : batched) {
+      const Param& p = c->params[i];
+      LoadDesc e{};
+      e.src = srcs[i]; e.numel = p.numel; e.dst = (long long)p.off; e.dst_t = p.has_t ? (long long)p.t_off : -1;
+      e.as_t = p.as_t ? 1 : 0; e.rows = p.rows; e.cols = p.cols; e.ld = p.ld; e.col0 = p.col0; e.O = p.O; e.I = p.I;
+      e.kind = p.kind == PK_F32 ? 0 : (p.kind == PK_MAT ? 1 : (p.kind == PK_CONV3 ? 2 : 3));
+      d.push_back(e);
+    }
+    hipError_t e = hipSuccess;
+    if (!c->load_descs) e = hipMalloc(reinterpret_cast<void**>(&c->load_descs), sizeof(LoadDesc) * c->params.size());
+    // pageable host memory: the copy is staged before the call returns, so the vector may go out of scope
+    if (e == hipSuccess) e = hipMemcpyAsync(c->load_descs, d.data(), sizeof(LoadDesc) * d.size(), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) { set_err("llie_load_all: %s", hipGetErrorString(e)); return (int)e; }
+    c->load_srcs.assign(srcs, srcs + n);
+  }
+  if (!batched.empty()) {
+    hipError_t e = launch_load_all(c->dt, c->load_descs, (int)batched.size(), c->blob, s);
+    if (e != hipSuccess) { set_err("llie_load_all: %s", hipGetErrorString(e)); return (int)e; }
+    for (int i : batched) c->params[i].loaded = true;
+  }
+  for (int i = 0; i < n; ++i) {
+    const PKind k = c->params[i].kind;
+    if (k == PK_INIT || k == PK_FINAL) {
+      const int rc = llie_load_param(c, c->params[i].key.c_str(), srcs[i], c->params[i].numel, stream);
+      if (rc) return rc;
+    }
+  }
   return LLIE_OK;
 }
 

@@ -223,6 +223,17 @@ hipError_t launch_repack_final(const float* src, float* dst, int O, int I, hipSt
 hipError_t launch_repack_final_mfma(int dtype, const float* src, void* dst, int O, int I, hipStream_t s);    // OIHW -> [I/32][18][2][4][8] T
 hipError_t launch_repack_init_mfma(int dtype, const float* src, void* dst, int O, int I, hipStream_t s);     // OIHW -> [5][2][O][8] T
 
+// All plain / matrix / 3x3 / depthwise parameters in ONE launch (an optimiser step changes every parameter: 300+
+// small repack launches would cost more than the repack itself).  Offsets are bytes into the weight blob; -1 = none.
+struct LoadDesc {
+  const float* src;
+  int kind;            // 0 fp32 copy, 1 matrix (cvt_rows [+ transposed copy]), 2 OIHW 3x3 ([tap][O][I] [+ [8-tap][I][O]]), 3 depthwise ([tap][C] + flipped)
+  int as_t;            // matrix: destination in the compute dtype (1) or fp32 (0)
+  int rows, cols, ld, col0, O, I;
+  long long numel, dst, dst_t;
+};
+hipError_t launch_load_all(int dtype, const LoadDesc* descs_dev, int n, char* blob, hipStream_t s);
+
 // uint8 HWC RGB <-> normalised fp32 NCHW with bilinear resize (scripts/inference.py:99-134), bit-exact with hostio.py.
 hipError_t launch_preprocess_u8(const uint8_t* img, int B, int H0, int W0, float* out, int S, hipStream_t s);
 hipError_t launch_postprocess_u8(const float* x, int B, int S, uint8_t* img, int H0, int W0, hipStream_t s);

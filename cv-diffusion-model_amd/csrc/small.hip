@@ -619,6 +619,43 @@ hipError_t launch_repack_dw_flip(const float* src, float* dst, int C, hipStream_
   return hipGetLastError();
 }
 
+template <typename T>
+__global__ void __launch_bounds__(256) load_all_kernel(const LoadDesc* descs, char* blob) {
+  const LoadDesc d = descs[blockIdx.y];
+  const float* src = d.src;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < d.numel; i += (long long)gridDim.x * 256) {
+    const float v = src[i];
+    if (d.kind == 0) {
+      reinterpret_cast<float*>(blob + d.dst)[i] = v;
+    } else if (d.kind == 1) {
+      const int r = (int)(i / d.cols), c = (int)(i % d.cols);
+      const size_t o = (size_t)r * d.ld + d.col0 + c;
+      if (d.as_t) reinterpret_cast<T*>(blob + d.dst)[o] = (T)v;
+      else reinterpret_cast<float*>(blob + d.dst)[o] = v;
+      if (d.dst_t >= 0) reinterpret_cast<T*>(blob + d.dst_t)[(size_t)c * d.rows + r] = (T)v;
+    } else if (d.kind == 2) {
+      const int tap = (int)(i % 9);
+      const int ci = (int)((i / 9) % d.I), co = (int)(i / (9 * (long long)d.I));
+      reinterpret_cast<T*>(blob + d.dst)[((size_t)tap * d.O + co) * d.I + ci] = (T)v;
+      if (d.dst_t >= 0) reinterpret_cast<T*>(blob + d.dst_t)[((size_t)(8 - tap) * d.I + ci) * d.O + co] = (T)v;
+    } else {
+      const int tap = (int)(i % 9), c = (int)(i / 9);
+      reinterpret_cast<float*>(blob + d.dst)[(size_t)tap * d.O + c] = v;
+      if (d.dst_t >= 0) reinterpret_cast<float*>(blob + d.dst_t)[(size_t)(8 - tap) * d.O + c] = v;
+    }
+  }
+}
+hipError_t launch_load_all(int dtype, const LoadDesc* descs_dev, int n, char* blob, hipStream_t s) {
+  dim3 grid(32, n);
+  switch (dtype) {
+    case 0: hipLaunchKernelGGL(load_all_kernel<float>, grid, dim3(256), 0, s, descs_dev, blob); break;
+    case 1: hipLaunchKernelGGL(load_all_kernel<half_t>, grid, dim3(256), 0, s, descs_dev, blob); break;
+    case 2: hipLaunchKernelGGL(load_all_kernel<bf16_t>, grid, dim3(256), 0, s, descs_dev, blob); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
 // init_conv OIHW [O][I][3][3] -> [I*9][O];  final_conv OIHW [O<=4][I][3][3] -> [9][I][4] zero padded
 __global__ void repack_init_kernel(const float* src, float* dst, int O, int I) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;

@@ -195,11 +195,13 @@ class _NativeModule(nn.Module):
             h = entry[0] if entry is not None else N.Handle(self._make_cfg(dtype_code))
             stream = torch.cuda.current_stream(dev).cuda_stream
             sd = dict(self.named_parameters())
+            ts = []
             for k, _ in self._param_list:
                 t = sd[k].detach()
                 if t.dtype != torch.float32 or not t.is_contiguous():
                     t = t.float().contiguous()
-                h.load_param(k, t, stream)
+                ts.append(t)
+            h.load_all(ts, stream)  # one repack launch for (almost) everything: an optimiser step touches every tensor
         self._handles[key] = (h, sig)
         return h
 

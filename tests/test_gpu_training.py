@@ -301,3 +301,43 @@ def test_unet_backward_large64_and_small128(dev):
             if not (l2 < 2e-2 and cs > 0.9995):
                 bad[k] = (l2, cs)
         assert not bad, f"{variant}@{size}: {len(bad)} tensors off: {dict(list(bad.items())[:8])}"
+
+
+def test_fp16_amp_with_default_gradscaler_and_grad_accumulation(dev):
+    """fp16 autocast with GradScaler's default 65536 scale (trainer.py:176-181): overflowing steps are skipped and the
+    scale backs off, finite steps update the weights; two backward passes accumulate into `.grad` like any autograd op."""
+    m, sd, spec = _small(64, dev)
+    m.load_state_dict(sd)
+    low = (torch.rand(2, 3, 64, 64, generator=torch.Generator().manual_seed(1)) * 2 - 1).to(dev)
+    normal = (torch.rand(2, 3, 64, 64, generator=torch.Generator().manual_seed(2)) * 2 - 1).to(dev)
+    opt = torch.optim.AdamW(m.parameters(), lr=1e-5)
+    scaler = torch.amp.GradScaler("cuda")
+    before = {k: p.detach().clone() for k, p in m.named_parameters()}
+    stepped = 0
+    for _ in range(4):
+        opt.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=torch.float16):
+            loss = m.compute_loss(low, normal)
+        scaler.scale(loss).backward()
+        scaler.unscale_(opt)
+        finite = all(torch.isfinite(p.grad).all() for p in m.parameters())
+        torch.nn.utils.clip_grad_norm_(m.parameters(), 1.0)
+        scaler.step(opt)
+        scaler.update()
+        stepped += int(finite)
+    assert torch.isfinite(loss)
+    assert stepped >= 1 or scaler.get_scale() < 65536.0
+    if stepped:
+        assert any(not torch.equal(before[k], p.detach()) for k, p in m.named_parameters())
+    # accumulation: backward twice == 2 x backward once (fp32 engine, same inputs)
+    m.load_state_dict(sd)
+    t = torch.tensor([10, 700], device=dev)
+    noise = torch.randn(2, 3, 64, 64, device=dev)
+    m.zero_grad(set_to_none=True)
+    out = m(low, normal, timesteps=t, noise=noise)
+    torch.nn.functional.mse_loss(out["noise_pred"], out["noise"]).backward()
+    g1 = {k: p.grad.clone() for k, p in m.named_parameters()}
+    out = m(low, normal, timesteps=t, noise=noise)
+    torch.nn.functional.mse_loss(out["noise_pred"], out["noise"]).backward()
+    for k, p in m.named_parameters():
+        assert torch.allclose(p.grad, 2 * g1[k], rtol=1e-6, atol=0), k
