@@ -121,7 +121,7 @@ __device__ __forceinline__ void pool_segment_flush(float (&psum)[VEC], float* re
 //   pool[b][(seg_y * tiles_x + tx)][c],  seg_y = global 8-row segment index.  red = [nseg][NW][CC].
 template <int CC, int NT>
 __device__ __forceinline__ void pool_segments_store(const float* red, int nseg, int tid, float* pool_img /* + b*ntiles*C + cbase */,
-                                                    int C, int seg_y0, int tiles_x, int tx) {
+                                                    int C /* floats between consecutive slab entries */, int seg_y0, int tiles_x, int tx) {
   constexpr int NW = NT / 64;
   for (int i = tid; i < nseg * CC; i += NT) {
     const int seg = i / CC, c = i % CC;

@@ -33,8 +33,12 @@ __device__ __forceinline__ void fma_mix_f16(float& acc, uint32_t w2, uint32_t f2
 
 constexpr int kDwPF = 4;  // rows of global loads kept in flight per thread
 
-template <typename T, int TX, int PFV>
-__global__ void __launch_bounds__(8 * TX) dwconv3x3_kernel(const DwArgs a, const int TYL, const int dbg, const int swap) {
+// BWD = true is the training backward's instantiation (input gradient of the depthwise conv): the epilogue
+// multiplies each output by the ReLU6 derivative of the forward pre-activation z = bx*bas + bab (bx = the tensor the
+// forward depthwise read) and writes per-8-row-segment partial sums (sum dz, sum dz*bx) for the GroupNorm backward,
+// in place of the SE pool partials.  The forward instantiation (BWD = false) compiles none of it.
+template <typename T, int TX, int PFV, bool BWD>
+__device__ __forceinline__ void dw_body(const DwArgs& a, const int TYL, const int dbg, const int swap) {
   constexpr int NT = 8 * TX;
   constexpr int VEC = Elem<T>::VEC;
   constexpr int CC = 8 * VEC;  // channels per workgroup
@@ -42,7 +46,7 @@ __global__ void __launch_bounds__(8 * TX) dwconv3x3_kernel(const DwArgs a, const
   constexpr int PF = PFV;
   typedef typename Elem<T>::vec_t vec_t;
   __shared__ vec_t ring[2][PW * 8];
-  __shared__ float red[8 * (NT / 64) * CC];  // [8-row segment of the strip][wave][channel]
+  __shared__ float red[(BWD ? 2 : 1) * 8 * (NT / 64) * CC];  // [8-row segment of the strip][wave][channel] (x2: BWD)
 
   const int tid = threadIdx.x, cl = tid & 7, xl = tid >> 3;
   const int tiles_x = a.W / TX;
@@ -95,8 +99,28 @@ __global__ void __launch_bounds__(8 * TX) dwconv3x3_kernel(const DwArgs a, const
 #pragma unroll
   for (int e = 0; e < VEC; ++e) zero[e] = (T)0.f;
 
+  // BWD: the forward input at the output pixel, fetched PF rows ahead like the input rows
+  const T* bx = BWD ? reinterpret_cast<const T*>(a.bx) + (size_t)b * a.H * a.W * a.C + c0 : nullptr;
+  vec_t preb[PF];
+  float bsc[VEC], bsh[VEC], psum2[VEC];
+  if constexpr (BWD) {
 #pragma unroll
-  for (int j = 0; j < PF; ++j) issue(j, pre[j], preh[j]);
+    for (int e = 0; e < VEC; ++e) {
+      bsc[e] = a.bas[(size_t)b * a.C + c0 + e];
+      bsh[e] = a.bab[(size_t)b * a.C + c0 + e];
+      psum2[e] = 0.f;
+    }
+  }
+  auto issue_b = [&](int r, vec_t& v) {  // output row r - 2 is produced at iteration r
+    if constexpr (BWD) {
+      if (r >= 2 && r < nrows) v = ld_vec<T>(bx + ((size_t)(y0 + r - 2) * a.W + x0 + xl) * a.C);
+    }
+  };
+#pragma unroll
+  for (int j = 0; j < PF; ++j) {
+    issue(j, pre[j], preh[j]);
+    issue_b(j, preb[j]);
+  }
 
   // acc[o % 3] accumulates output row o.  The row loop is unrolled 12-fold (lcm of the prefetch depth 4
   // and the 3 accumulator roles) so that accumulator indices, prefetch slots and the ring buffer parity
@@ -153,24 +177,58 @@ __global__ void __launch_bounds__(8 * TX) dwconv3x3_kernel(const DwArgs a, const
           }
       }
       if (r >= 2) {
-        vec_t ov = f32_to_vec<T>(a2);
-        st_vec<T>(out + ((size_t)(y0 + r - 2) * a.W + x0 + xl) * a.C, ov);
+        if constexpr (BWD) {
+          float hb[VEC], dz[VEC];
+          vec_to_f32<T>(preb[j % 4], hb);
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) psum[e] += (float)ov[e];
-        if (a.pool && ((r - 2) & 7) == 7)  // uniform: an 8-row pool segment is complete
-          pool_segment_flush<VEC>(psum, red + (((r - 2) >> 3) * (NT / 64) + (tid >> 6)) * CC, tid & 63);
+          for (int e = 0; e < VEC; ++e) {
+            const float z = hb[e] * bsc[e] + bsh[e];
+            dz[e] = round_to<T>((z > 0.f && z < 6.f) ? a2[e] : 0.f);
+            psum[e] += dz[e];
+            psum2[e] += dz[e] * hb[e];
+          }
+          st_f32<T>(out + ((size_t)(y0 + r - 2) * a.W + x0 + xl) * a.C, dz);
+          if (((r - 2) & 7) == 7) {  // uniform: an 8-row segment is complete
+            pool_segment_flush<VEC>(psum, red + (((r - 2) >> 3) * (NT / 64) + (tid >> 6)) * CC, tid & 63);
+            pool_segment_flush<VEC>(psum2, red + ((8 + ((r - 2) >> 3)) * (NT / 64) + (tid >> 6)) * CC, tid & 63);
+          }
+        } else {
+          vec_t ov = f32_to_vec<T>(a2);
+          st_vec<T>(out + ((size_t)(y0 + r - 2) * a.W + x0 + xl) * a.C, ov);
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) psum[e] += (float)ov[e];
+          if (a.pool && ((r - 2) & 7) == 7)  // uniform: an 8-row pool segment is complete
+            pool_segment_flush<VEC>(psum, red + (((r - 2) >> 3) * (NT / 64) + (tid >> 6)) * CC, tid & 63);
+        }
       }
+      issue_b(r + PF, preb[j % 4]);
 #pragma unroll
       for (int e = 0; e < VEC; ++e) a2[e] = 0.f;  // slot becomes the accumulator of output row r+1
     }
   }
   // ---- SE pool partials, one per 8-row segment (layout independent of the strip height)
-  if (a.pool) {
+  if constexpr (BWD) {  // slab[b][tile][{sum dz, sum dz*bx}][C]
+    __syncthreads();
+    const int ntiles = tiles_x * (a.H / kPoolSegRows);
+    float* base = a.bslab + (size_t)b * ntiles * 2 * a.C + chunk_id * CC;
+    pool_segments_store<CC, NT>(red, TYL / kPoolSegRows, tid, base, 2 * a.C, ty * (TYL / kPoolSegRows), tiles_x, tx);
+    pool_segments_store<CC, NT>(red + 8 * (NT / 64) * CC, TYL / kPoolSegRows, tid, base + a.C, 2 * a.C,
+                                ty * (TYL / kPoolSegRows), tiles_x, tx);
+  } else if (a.pool) {
     __syncthreads();
     const int ntiles = tiles_x * (a.H / kPoolSegRows);
     pool_segments_store<CC, NT>(red, TYL / kPoolSegRows, tid, a.pool + (size_t)b * ntiles * a.C + chunk_id * CC, a.C,
                                 ty * (TYL / kPoolSegRows), tiles_x, tx);
   }
+}
+
+template <typename T, int TX, int PFV>
+__global__ void __launch_bounds__(8 * TX) dwconv3x3_kernel(const DwArgs a, const int TYL, const int dbg, const int swap) {
+  dw_body<T, TX, PFV, false>(a, TYL, dbg, swap);
+}
+template <typename T, int TX, int PFV>
+__global__ void __launch_bounds__(8 * TX) dwconv3x3_bwd_kernel(const DwArgs a, const int TYL, const int swap) {
+  dw_body<T, TX, PFV, true>(a, TYL, 0, swap);
 }
 
 static int g_dw_swap = 0;
@@ -201,6 +259,13 @@ static hipError_t launch_dw_t(const DwArgs& a, hipStream_t s) {
                                        std::string("dwconv3x3_kernel<") + TypeName<T>::value + ", 16, 4>",
                                        std::string("dwconv3x3_kernel<") + TypeName<T>::value + ", 8, 4>"};
   note_kernel(names[tx == 32 ? 0 : (tx == 16 ? 1 : 2)].c_str());
+  if (a.bx) {  // backward instantiation
+    if (!a.bas || !a.bab || !a.bslab || a.pool) return hipErrorInvalidValue;
+    if (tx == 32) hipLaunchKernelGGL((dwconv3x3_bwd_kernel<T, 32, kDwPF>), grid, dim3(256), 0, s, a, tyl, g_dw_swap);
+    else if (tx == 16) hipLaunchKernelGGL((dwconv3x3_bwd_kernel<T, 16, kDwPF>), grid, dim3(128), 0, s, a, tyl, g_dw_swap);
+    else hipLaunchKernelGGL((dwconv3x3_bwd_kernel<T, 8, kDwPF>), grid, dim3(64), 0, s, a, tyl, g_dw_swap);
+    return hipGetLastError();
+  }
   if (tx == 32) hipLaunchKernelGGL((dwconv3x3_kernel<T, 32, kDwPF>), grid, dim3(256), 0, s, a, tyl, g_dw_dbg & 3, g_dw_swap);
   else if (tx == 16) hipLaunchKernelGGL((dwconv3x3_kernel<T, 16, kDwPF>), grid, dim3(128), 0, s, a, tyl, g_dw_dbg & 3, g_dw_swap);
   else hipLaunchKernelGGL((dwconv3x3_kernel<T, 8, kDwPF>), grid, dim3(64), 0, s, a, tyl, g_dw_dbg & 3, g_dw_swap);

@@ -896,11 +896,12 @@ struct Back {
   }
 
   // out[M][N] = in[M][K] * W[N][K]^T on the forward GEMM kernel (W = a transposed weight copy)
-  void gemm(size_t in, int K, const void* w, size_t out, int N, int M, int P) {
+  void gemm(size_t in, int K, const void* w, size_t out, int N, int M, int P, size_t slab = 0, size_t dot = 0, bool with_dot = false) {
     if (dry) return;
     GemmArgs g{};
     g.seg[0] = GemmSeg{p(in), K, nullptr, nullptr, 0, ACT_NONE};
     g.nseg = 1; g.w = w; g.out = p(out); g.M = M; g.N = N; g.K = K; g.P = P;
+    if (with_dot) { g.stats = p<float>(slab); g.dot = p(dot); }  // slab[b][tile][0][n] = sum over the tile's rows of out*dot
     chk(launch_pw_gemm(dt, g, s));
   }
   struct Geo { int Ho, Wo, Hi, Wi, stride, dy, dx; };
@@ -923,10 +924,14 @@ struct Back {
   // activation backward + GroupNorm backward coefficients + norm parameter gradients at one norm site.
   //   g: gradient w.r.t. the activation output act(norm(x)) [M][C]; dz is written over g when act != none.
   struct Coef { size_t A, Bq, Cq; };
+  //   pre_slab / pre_tiles: the producer already applied the activation derivative and wrote the partial sums
+  //   (depthwise backward epilogue); then only the reduction and the coefficient kernels run here.
   Coef gn_site(size_t g, const Tens& x0, const Tens* x1, const GnRec& rec, int act, size_t gamma, size_t beta,
-               float* dgamma, float* dbeta, const float* film, int64_t fstride, float* dfilm, int64_t dfstride) {
-    const int C = x0.C + (x1 ? x1->C : 0), P = x0.H * x0.W, M = B * P, nt = P / 64;
-    const size_t slab = alloc((size_t)B * nt * 2 * C * 4), S = alloc((size_t)B * 2 * C * 4);
+               float* dgamma, float* dbeta, const float* film, int64_t fstride, float* dfilm, int64_t dfstride,
+               size_t pre_slab = 0, int pre_tiles = 0) {
+    const int C = x0.C + (x1 ? x1->C : 0), P = x0.H * x0.W, M = B * P, nt = pre_tiles ? pre_tiles : P / 64;
+    const size_t slab = pre_tiles ? pre_slab : alloc((size_t)B * nt * 2 * C * 4);
+    const size_t S = alloc((size_t)B * 2 * C * 4);
     Coef k{alloc((size_t)B * C * 4), alloc((size_t)B * C * 4), alloc((size_t)B * C * 4)};
     const size_t dG = alloc((size_t)B * C * 4), dBc = alloc((size_t)B * C * 4);
     if (!dry) {
@@ -934,7 +939,7 @@ struct Back {
       m.g = p(g); m.x0 = p(x0.off); m.c0 = x0.C; m.x1 = x1 ? p(x1->off) : nullptr; m.c1 = x1 ? x1->C : 0;
       m.as = p<float>(rec.as); m.ab = p<float>(rec.ab); m.act = act; m.dz = act == ACT_NONE ? nullptr : p(g);
       m.slab = p<float>(slab); m.M = M; m.C = C; m.P = P;
-      chk(launch_bwd_mask_reduce(dt, m, s));
+      if (!pre_tiles) chk(launch_bwd_mask_reduce(dt, m, s));
       chk(launch_slab_reduce(p<float>(slab), p<float>(S), B, nt, 2, 2, C, s));
       GnBwdArgs a{};
       a.S = p<float>(S); a.mean = p<float>(rec.mean); a.rstd = p<float>(rec.rstd); a.gamma = wptr<float>(gamma);
@@ -947,7 +952,8 @@ struct Back {
       q.B = B; q.C = C;
       chk(launch_gn_param_grad(q, s));
     }
-    ar->free(slab); ar->free(S); ar->free(dG); ar->free(dBc);
+    if (!pre_tiles) ar->free(slab);
+    ar->free(S); ar->free(dG); ar->free(dBc);
     return k;
   }
   void free_coef(const Coef& k) { ar->free(k.A); ar->free(k.Bq); ar->free(k.Cq); }
@@ -971,7 +977,9 @@ struct Back {
     const Geo g11{H, W, H, W, 1, 0, 0};
     // project (+ skip) input gradients
     const size_t da3 = alloc((size_t)M * hid * es());
-    gemm(dY, cout, wptr(w.w_proj_t), da3, hid, M, P);
+    const int gtiles = P / pw_gemm_tile_rows(P);
+    const size_t gslab = alloc((size_t)B * gtiles * 2 * hid * 4);  // d(gate) partials from the GEMM's epilogue: sum_px da3*h2
+    gemm(dY, cout, wptr(w.w_proj_t), da3, hid, M, P, gslab, r.h2, true);
     size_t dxs = 0;
     if (w.skip) {
       dxs = alloc((size_t)M * cin * es());
@@ -991,14 +999,9 @@ struct Back {
     const size_t dgate = alloc((size_t)B * hid * 4), dpre2 = alloc((size_t)B * hid * 4), dr = alloc((size_t)B * w.sq * 4);
     const size_t dmean = alloc((size_t)B * hid * 4);
     {
-      const int nt = P / 64;
-      const size_t slab = alloc((size_t)B * nt * 2 * hid * 4);
       const size_t sescr = alloc((size_t)std::max(linear_dx_chunks(hid) * w.sq, linear_dx_chunks(w.sq) * hid) * B * 4);
       if (!dry) {
-        BwdMaskArgs m{};
-        m.g = p(da3); m.x0 = p(r.h2); m.c0 = hid; m.act = ACT_NONE; m.slab = p<float>(slab); m.M = M; m.C = hid; m.P = P;
-        chk(launch_bwd_mask_reduce(dt, m, s));
-        chk(launch_slab_reduce(p<float>(slab) + hid, p<float>(dgate), B, nt, 2, 1, hid, s));
+        chk(launch_slab_reduce(p<float>(gslab), p<float>(dgate), B, gtiles, 2, 1, hid, s));
         chk(launch_sigmoid_bwd(p<float>(dgate), p<float>(r.gate), p<float>(dpre2), (int64_t)B * hid, s));
         chk(launch_linear_dw(p<float>(dpre2), hid, p<float>(r.sehid), gp(pf + 8), gp(pf + 9), B, hid, w.sq, s));
         chk(launch_linear_dx(dt, p<float>(dpre2), hid, wptr(w.se_w2), p<float>(dr), B, hid, w.sq, s, p<float>(sescr)));
@@ -1007,16 +1010,19 @@ struct Back {
         chk(launch_linear_dx(dt, p<float>(dr), w.sq, wptr(w.se_w1), p<float>(dmean), B, w.sq, hid, s, p<float>(sescr)));
         chk(launch_scale_rows(p<float>(dmean), p<float>(dmean), (int64_t)B * hid, 1.f / (float)P, s));
       }
-      ar->free(slab); ar->free(sescr);
+      ar->free(gslab); ar->free(sescr);
     }
     // depthwise: input gradient (same kernel, flipped taps, prologue dh2 = da3*gate + dmean/P) and weight gradient
     const size_t da2 = alloc((size_t)M * hid * es());
+    const int dztiles = dwconv_ntiles(H, W);
+    const size_t dzslab = alloc((size_t)B * dztiles * 2 * hid * 4);
     {
       const size_t part = alloc((size_t)B * dw_wgrad_strips(H, W) * 9 * hid * 4);
       if (!dry) {
-        DwArgs d{};
+        DwArgs d{};  // writes dz2 = da2 * relu6'(norm2(h1)) and the (sum dz, sum dz*h1) partials in its epilogue
         d.in = p(da3); d.out = p(da2); d.as = p<float>(r.gate); d.ab = p<float>(dmean); d.w = wptr<float>(w.w_dw_flip);
         d.pool = nullptr; d.B = B; d.H = H; d.W = W; d.C = hid; d.no_act = 1;
+        d.bx = p(r.h1.off); d.bas = p<float>(r.n2.as); d.bab = p<float>(r.n2.ab); d.bslab = p<float>(dzslab);
         chk(launch_dwconv3x3(dt, d, s));
         DwWgradArgs q{};
         q.g = p(da3); q.gs = p<float>(r.gate); q.gb = p<float>(dmean); q.h = p(r.h1.off); q.as = p<float>(r.n2.as);
@@ -1029,7 +1035,8 @@ struct Back {
     // norm2 + FiLM + ReLU6
     const float* film = dry ? nullptr : p<float>(tp->film) + w.film_off;
     float* dfl = dry ? nullptr : p<float>(dfilm) + w.film_off;
-    Coef k2 = gn_site(da2, r.h1, nullptr, r.n2, ACT_RELU6, w.n2g, w.n2b, gp(pf + 2), gp(pf + 3), film, F, dfl, F);
+    Coef k2 = gn_site(da2, r.h1, nullptr, r.n2, ACT_RELU6, w.n2g, w.n2b, gp(pf + 2), gp(pf + 3), film, F, dfl, F, dzslab, dztiles);
+    ar->free(dzslab);
     apply(da2, r.h1, nullptr, k2, 0, false, 0, false, 0, false, da2, 0);  // dh1, in place
     free_coef(k2);
     // expand
@@ -1816,6 +1823,7 @@ int llie_tune(const char* knob, int value) {
   if (!strcmp(knob, "gemm_ablate")) { pw_gemm_debug(value); return LLIE_OK; }
   if (!strcmp(knob, "dw_ablate")) { dwconv_debug(value); return LLIE_OK; }
   if (!strcmp(knob, "dw_swap")) { dwconv_swap(value); return LLIE_OK; }
+  if (!strcmp(knob, "wgrad_target")) { wgrad_set_target(value); return LLIE_OK; }
   return LLIE_ERR_ARG;
 }
 

@@ -177,6 +177,7 @@ __global__ void __launch_bounds__(WM* WN * 64) pw_gemm_kernel(const GemmArgs g) 
   }
   T* outp = reinterpret_cast<T*>(g.out);
   const T* resp = reinterpret_cast<const T*>(g.res);
+  const T* dotp = reinterpret_cast<const T*>(g.dot);
 #pragma unroll
   for (int pi = 0; pi < MI; ++pi) {
     if (pi) __syncthreads();  // previous pass fully read
@@ -209,11 +210,22 @@ __global__ void __launch_bounds__(WM* WN * 64) pw_gemm_kernel(const GemmArgs g) 
       vec_t ov = f32_to_vec<T>(v);
       if (!g.nostore) st_vec<T>(outp + o, ov);  // nostore: statistics-only pass (the consumer recomputes the tensor)
       if (g.stats) {
+        if (dotp) {  // backward use: column sums of out * dot (e.g. d(gate) = sum_px da3 * h2) instead of sum / sum of squares
+          float dd[VEC];
+          ld_f32<T>(dotp + o, dd);
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) {
-          const float q = (float)ov[e];
-          s1[grp][e] += q;
-          s2[grp][e] += q * q;
+          for (int e = 0; e < VEC; ++e) {
+            const float q = (float)ov[e];
+            s1[grp][e] += q * dd[e];
+            s2[grp][e] += q;
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) {
+            const float q = (float)ov[e];
+            s1[grp][e] += q;
+            s2[grp][e] += q * q;
+          }
         }
       }
     }

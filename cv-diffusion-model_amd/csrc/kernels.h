@@ -47,6 +47,7 @@ struct GemmArgs {
   int P;              // rows (pixels) per image; M = B * P
   int nostore;        // 1: compute and write only the statistics slab (out may be null)
   int dbg;            // timing ablations (set by the launcher from pw_gemm_debug; 0 in production)
+  const void* dot;    // optional [M][N] T: the slab then holds (sum out*dot, sum out) instead of (sum, sum of squares)
 };
 hipError_t launch_pw_gemm(int dtype, const GemmArgs& a, hipStream_t s);
 bool pw_gemm2_supported(int dtype, const GemmArgs& a);   // LDS-DMA pipelined variant (gemm2.hip)
@@ -87,6 +88,9 @@ struct DwArgs {
   float* pool;
   int B, H, W, C;
   int no_act;        // 1: prologue is the affine alone (backward: dh2 = da3*gate + dmean/P), 0: affine + ReLU6
+  // backward epilogue (all four set, pool null): out = conv * [0 < bx*bas + bab < 6], and
+  // bslab[b][tile][0][c] = sum out, [1][c] = sum out*bx over 8-row segments (tile = dwconv_ntiles numbering)
+  const void* bx; const float* bas; const float* bab; float* bslab;
 };
 hipError_t launch_dwconv3x3(int dtype, const DwArgs& a, hipStream_t s);
 
@@ -313,6 +317,7 @@ struct WgradArgs {
   int msplit;
 };
 int wgrad_msplit(int dtype, int M, int N, int K, int ntap);
+void wgrad_set_target(int workgroups);  // tuning knob: workgroups per launch the row split aims for (default 1024)
 hipError_t launch_wgrad(int dtype, const WgradArgs& a, hipStream_t s);
 
 // (5) depthwise 3x3 weight gradient: dw[c][tap] (reference layout [C][1][3][3]) =

@@ -206,13 +206,15 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* partial,
 }
 
 // number of row splits: enough workgroups to fill the GPU, each split a multiple of 64 rows
+static int g_wgrad_target = 1024;  // workgroups per launch the row split aims for
+void wgrad_set_target(int v) { g_wgrad_target = v > 0 ? v : 1024; }
 // 128x128 tiles for the wide layers of the 2-byte engines (fp32 tiles would not fit the 64 KB static LDS)
 static int wgrad_tile(int dtype, int N, int K) { return (dtype != 0 && N >= 128 && K > 64) ? 128 : 64; }
 int wgrad_msplit(int dtype, int M, int N, int K, int ntap) {
   const int t = wgrad_tile(dtype, N, K);
   const int tiles = ((N + t - 1) / t) * ((K + t - 1) / t) * ntap;
   int ms = 1;
-  while (tiles * ms < 2048 && M % (ms * 2 * kWgRows) == 0 && M / (ms * 2) >= 256) ms *= 2;
+  while (tiles * ms < g_wgrad_target && M % (ms * 2 * kWgRows) == 0 && M / (ms * 2) >= 256) ms *= 2;
   return ms;
 }
 
