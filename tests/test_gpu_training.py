@@ -341,3 +341,14 @@ def test_fp16_amp_with_default_gradscaler_and_grad_accumulation(dev):
     torch.nn.functional.mse_loss(out["noise_pred"], out["noise"]).backward()
     for k, p in m.named_parameters():
         assert torch.allclose(p.grad, 2 * g1[k], rtol=1e-6, atol=0), k
+
+
+def test_data_parallel_gradients_two_ranks_one_gpu(dev):
+    """Config 5's data-parallel step with two ranks sharing this GPU over gloo (RCCL wants one device per rank; the
+    collective call is the same): half batches + all_reduce_gradients == full-batch gradients, with ONE all_reduce
+    because the engine's gradients alias a single flat buffer (tools/gpu_ddp_check.py)."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "gpu_ddp_check.py")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    assert r.stdout.count("1 all_reduce call(s)") == 2
