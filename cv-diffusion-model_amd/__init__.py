@@ -14,6 +14,8 @@ from .scheduler import LCMScheduler, LCMSchedulerOutput, LCMDenoisingLoop, get_l
 from .pipeline import LowLightDiffusion, LowLightDiffusionOutput, normalize_image, denormalize_image
 from .sharding import shard_range, enhance_sharded, all_gather_batch, all_reduce_gradients
 from .build import build_library, library_path
+from . import ops  # registers torch.ops.llie.*
+from .ops import register_model
 from .hostio import (load_checkpoint, extract_state_dict, preprocess_array, postprocess_array, resize_bilinear,
                      preprocess_device, postprocess_device)
 
@@ -21,6 +23,6 @@ __all__ = [
     "EfficientUNet", "EfficientUNetConfig", "create_efficient_unet", "InvertedResidualBlock", "LinearAttention",
     "Downsample", "Upsample", "LCMScheduler", "LCMSchedulerOutput", "LCMDenoisingLoop", "get_lcm_timesteps", "LowLightDiffusion",
     "LowLightDiffusionOutput", "normalize_image", "denormalize_image", "shard_range", "enhance_sharded",
-    "all_gather_batch", "all_reduce_gradients", "build_library", "library_path", "load_checkpoint", "extract_state_dict",
+    "all_gather_batch", "all_reduce_gradients", "register_model", "build_library", "library_path", "load_checkpoint", "extract_state_dict",
     "preprocess_array", "postprocess_array", "resize_bilinear", "preprocess_device", "postprocess_device",
 ]

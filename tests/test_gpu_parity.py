@@ -424,3 +424,23 @@ def test_sharded_enhance_equals_single_process(dev):
         lo, hi = M.shard_range(6, r, 2)
         parts.append(m.enhance(low[lo:hi], 4, noise=noise[:, lo:hi]))
     assert torch.equal(torch.cat(parts), full)
+
+
+def test_custom_ops_match_module_methods(dev):
+    """torch.ops.llie.{enhance, unet_forward, lcm_step} run the same engine calls as the module methods."""
+    m, sd, spec = small_model(64, dev)
+    m.compute_dtype = None
+    mid = M.register_model(m)
+    low = (torch.rand(2, 3, 64, 64, generator=torch.Generator().manual_seed(4)) * 2 - 1).to(dev)
+    noise = torch.stack(oracle.draw_noise(2, 64, 4, seed=9)).to(dev)
+    assert torch.equal(torch.ops.llie.enhance(mid, low, noise, 4), m.enhance(low, 4, noise=noise))
+    t = torch.tensor([739, 19], device=dev)
+    with torch.no_grad():
+        ref = m.unet.forward_split(noise[0], low, t)
+    assert torch.equal(torch.ops.llie.unet_forward(mid, noise[0], low, t), ref)
+    s = M.LCMScheduler(rescale_betas_zero_snr=True); s.set_timesteps(4, device=dev)
+    c = s.step_coefficients(739)
+    out = torch.ops.llie.lcm_step(ref, noise[0], noise[1], c.sqrt_alpha_t, c.sqrt_beta_t, c.sqrt_alpha_prev, c.sqrt_beta_prev, False, False)
+    assert torch.equal(out, s.step(ref, 739, noise[0], noise=noise[1]).prev_sample)
+    with pytest.raises(RuntimeError):
+        torch.ops.llie.enhance(12345, low, noise, 4)   # unknown model id

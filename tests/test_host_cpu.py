@@ -275,3 +275,18 @@ def test_all_reduce_gradients_world2_gloo(tmp_path):
     for p, o in zip(procs, outs):
         assert p.returncode == 0 and "ok" in o, o[-2000:]
     assert M.all_reduce_gradients([torch.nn.Parameter(torch.zeros(2))]) == 0   # no process group: no-op
+
+
+def test_custom_ops_are_registered_with_fake_kernels():
+    """torch.ops.llie.*: named operators with meta implementations (shape inference without a device) and no CPU path."""
+    from torch._subclasses.fake_tensor import FakeTensorMode
+    assert hasattr(torch.ops.llie, "enhance") and hasattr(torch.ops.llie, "unet_forward") and hasattr(torch.ops.llie, "lcm_step")
+    with FakeTensorMode():
+        low = torch.empty(2, 3, 64, 64)
+        noise = torch.empty(4, 2, 3, 64, 64)
+        out = torch.ops.llie.enhance(0, low, noise, 4)
+        assert tuple(out.shape) == (2, 3, 64, 64) and out.dtype == torch.float32
+        eps = torch.ops.llie.unet_forward(0, low, low, torch.empty(2, dtype=torch.long))
+        assert tuple(eps.shape) == (2, 3, 64, 64)
+    with pytest.raises((NotImplementedError, RuntimeError)):
+        torch.ops.llie.enhance(0, torch.zeros(1, 3, 64, 64), torch.zeros(4, 1, 3, 64, 64), 4)   # CPU tensors: no kernel
