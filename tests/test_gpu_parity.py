@@ -444,3 +444,22 @@ def test_custom_ops_match_module_methods(dev):
     assert torch.equal(out, s.step(ref, 739, noise[0], noise=noise[1]).prev_sample)
     with pytest.raises(RuntimeError):
         torch.ops.llie.enhance(12345, low, noise, 4)   # unknown model id
+
+
+def test_non_power_of_two_image_size_192(dev):
+    """image_size 192 -> levels 192, 96, 48, 24: strip widths 32/32/16/8, 64-row GEMM tiles at 24x24 (P = 576),
+    attention over N = 576 positions; one UNet forward (fp32) and a 4-step loop against the oracle, B=1."""
+    spec = oracle.make_spec("small", 192)
+    sd = oracle.synth_state_dict(oracle.param_shapes(spec))
+    m = M.LowLightDiffusion(unet_variant="small", image_size=192, num_inference_steps=4)
+    m.load_state_dict(sd)
+    m = m.to(dev).eval()
+    low = torch.rand(1, 3, 192, 192, generator=torch.Generator().manual_seed(21)) * 2 - 1
+    noise = oracle.draw_noise(1, 192, 4, seed=22)
+    t = torch.tensor([499])
+    with torch.no_grad():
+        eps = m.unet(torch.cat([noise[0], low], 1).to(dev), t.to(dev))
+    ref = oracle.unet_forward(sd, spec, torch.cat([noise[0], low], 1), t)
+    assert max_abs(eps.cpu(), ref) < 1e-3
+    out = m.enhance(low.to(dev), 4, noise=torch.stack(noise))
+    assert max_abs(out.cpu(), oracle.enhance_ref(sd, spec, low, 4, noise)["enhanced"]) < 1e-3
