@@ -57,7 +57,7 @@ def cpu_baseline(variant: str, size: int, steps: int, state_dict, budget_s: floa
     import oracle
     ncores = host_cores()
     torch.set_num_threads(ncores)
-    spec = oracle.make_spec(variant, size)
+    spec = oracle.make_spec(variant, size, allow_unpinned=variant in ("tiny", "base"))
     sd = {k: v.detach().cpu().float() for k, v in state_dict.items()}
     g = torch.Generator().manual_seed(1234)
     low = torch.rand(1, 3, size, size, generator=g) * 2 - 1
@@ -171,7 +171,8 @@ def main() -> None:
             dist.destroy_process_group()
         return
     model = M.LowLightDiffusion(unet_variant=args.variant, image_size=args.image_size,
-                                num_inference_steps=args.lcm_steps, compute_dtype=args.dtype).to(dev).eval()
+                                num_inference_steps=args.lcm_steps, compute_dtype=args.dtype,
+                                allow_unpinned_groupnorm=args.variant in ("tiny", "base"))  # opt-in, parity-unpinned.to(dev).eval()
     B, S = args.batch, args.image_size
     g = torch.Generator().manual_seed(1234 + rank)
     low = (torch.rand(B, 3, S, S, generator=g) * 2 - 1).to(dev)      # synthetic low-light batch, resident in HBM

@@ -44,7 +44,7 @@ class Config(C.Structure):
         ("kind", C.c_int), ("compute_dtype", C.c_int), ("in_channels", C.c_int), ("out_channels", C.c_int),
         ("base_channels", C.c_int), ("channel_multipliers", C.c_int * 4), ("num_res_blocks", C.c_int),
         ("expansion_ratio", C.c_int), ("time_embed_dim", C.c_int), ("num_attention_heads", C.c_int),
-        ("image_size", C.c_int), ("attention_resolutions", C.c_int * 2),
+        ("image_size", C.c_int), ("attention_resolutions", C.c_int * 2), ("allow_unpinned", C.c_int),
     ]
 
 

@@ -45,6 +45,7 @@ struct Param {
   size_t off = 0;                      // byte offset of the destination in the weight blob
   int rows = 0, cols = 0, ld = 0, col0 = 0;  // PK_MAT: [rows][cols] -> dst[r*ld + col0 + c]
   int O = 0, I = 0;
+  int Op = 0, Ip = 0;                  // padded destination dims of conv / depthwise layouts (0 = O / I)
   bool as_t = true;                    // PK_MAT: store as compute dtype (true) or fp32
   bool loaded = false;
   int ndim = 1;
@@ -56,8 +57,12 @@ struct Param {
   int64_t goff = 0;
 };
 
+// cin / cout / hid are the PHYSICAL channel counts of the tensors (multiples of 32; hid of 64 for 2-byte types);
+// *_r the reference's.  They differ only for the unpinned variants (tiny / base), whose odd channel counts are
+// zero-padded at the end of each tensor: zero weights and a zero norm affine keep the padding at exactly zero.
 struct IrbW {
   int cin, cout, hid, sq;
+  int cin_r, cout_r, hid_r;
   bool skip;
   size_t n1g, n1b, n2g, n2b, w_expand, w_dw, se_w1, se_b1, se_w2, se_b2, w_proj;
   int film_off;  // first row of this block inside the concatenated FiLM projection
@@ -71,7 +76,7 @@ struct AttnW {
   int p_first;
 };
 struct ConvW {
-  int c;
+  int c, c_r;
   size_t w, bias;
   size_t w_t;
   int p_first;
@@ -130,7 +135,17 @@ struct Tens {
   size_t off = 0, slab = 0;
   int C = 0, H = 0, W = 0, ntiles = 0;
   bool valid = false;
+  int Cr = 0;  // real channels (<= C; the rest is zero padding)
 };
+
+// GroupNorm(min(32, C), C) of the reference; for channel counts it cannot construct (tiny / base: 48, 144 ...) the
+// documented deviation: the largest divisor of C that is <= 32.  Identical whenever C is a multiple of 32 or C < 32 | 32.
+inline int gn_groups(int c) {
+  for (int g = std::min(32, c); g >= 1; --g)
+    if (c % g == 0) return g;
+  return 1;
+}
+inline int pad32(int c) { return (c + 31) / 32 * 32; }
 
 // ---------------------------------------------------------------------------------------------
 // Training tape: what the forward pass leaves in the workspace for the backward pass (offsets).
@@ -170,7 +185,9 @@ struct llie_ctx {
   std::vector<ConvW> downs, ups;
   std::vector<std::vector<Block>> enc, dec;
   std::vector<Block> mid;
-  std::vector<int> channels;
+  std::vector<int> channels;    // physical (padded) channels per level
+  std::vector<int> channels_r;  // the reference's
+  bool padded = false;          // some tensor carries zero padding (unpinned variant): inference only
   // UNet-level tensors
   size_t t_w1 = 0, t_b1 = 0, t_w3 = 0, t_b3 = 0, freqs = 0, film_w = 0, film_b = 0;
   int film_rows = 0;
@@ -224,11 +241,12 @@ struct Builder {
     c->params.push_back(p);
     return c->params.back();
   }
-  size_t f32(const std::string& key, int64_t n) {
-    const size_t o = reserve((size_t)n * 4);
+  size_t f32(const std::string& key, int64_t n, int64_t n_phys = 0) {  // n_phys: zero-padded length of the destination
+    const size_t o = reserve((size_t)std::max(n, n_phys) * 4);
     add(key, n, PK_F32, o);
     return o;
   }
+  int padh(int hid) const { return c->dt == LLIE_F32 ? pad32(hid) : (hid + 63) / 64 * 64; }  // depthwise: 64 channels per workgroup
   size_t es() const { return elem_size(c->dt); }
   // matrix [rows][cols] stored in compute dtype at an existing destination
   void mat_into(const std::string& key, int rows, int cols, size_t off, int ld, int col0, bool as_t = true) {
@@ -241,44 +259,53 @@ struct Builder {
     int i = 0;
     for (int64_t d : dims) p.shape[i++] = d;
   }
-  size_t mat(const std::string& key, int rows, int cols, size_t* t_off = nullptr) {
-    const size_t o = reserve((size_t)rows * cols * es());
-    mat_into(key, rows, cols, o, cols, 0);
+  size_t mat(const std::string& key, int rows, int cols, size_t* t_off = nullptr, int rows_p = 0, int cols_p = 0) {
+    rows_p = std::max(rows, rows_p); cols_p = std::max(cols, cols_p);
+    const size_t o = reserve((size_t)rows_p * cols_p * es());
+    mat_into(key, rows, cols, o, cols_p, 0);
     if (t_off) {
-      *t_off = reserve((size_t)rows * cols * es());
+      *t_off = reserve((size_t)rows_p * cols_p * es());
       c->params.back().has_t = true;
       c->params.back().t_off = *t_off;
     }
     return o;
   }
-  int add_irb(const std::string& p, int cin, int cout, int T, int e) {
+  // cin_r / cout_r: the reference's channel counts; x0_r: real channels of the first input segment (== cin_r unless
+  // the block reads a virtual concat, whose first segment must be unpadded so that real channels stay contiguous)
+  int add_irb(const std::string& p, int cin_r, int cout_r, int T, int e, int x0_r = 0) {
+    if (x0_r <= 0) x0_r = cin_r;
+    if (x0_r != cin_r && x0_r % 32) bad = true;  // a padded first concat segment would break the real-channel numbering
     IrbW w{};
-    w.cin = cin; w.cout = cout; w.hid = cin * e; w.sq = std::max(1, (int)(w.hid * 0.25));
-    w.skip = cin != cout;
+    w.cin_r = cin_r; w.cout_r = cout_r; w.hid_r = cin_r * e; w.sq = std::max(1, (int)(w.hid_r * 0.25));
+    w.cin = x0_r == cin_r ? pad32(cin_r) : x0_r + pad32(cin_r - x0_r);
+    w.cout = pad32(cout_r); w.hid = padh(w.hid_r);
+    if (w.cin != cin_r || w.cout != cout_r || w.hid != w.hid_r) c->padded = true;
+    w.skip = cin_r != cout_r;
     w.p_first = (int)c->params.size();
-    w.n1g = f32(p + ".norm1.weight", cin); w.n1b = f32(p + ".norm1.bias", cin);
-    w.n2g = f32(p + ".norm2.weight", w.hid); w.n2b = f32(p + ".norm2.bias", w.hid);
-    w.w_expand = mat(p + ".expand.weight", w.hid, cin, &w.w_expand_t);
+    w.n1g = f32(p + ".norm1.weight", cin_r, w.cin); w.n1b = f32(p + ".norm1.bias", cin_r, w.cin);
+    w.n2g = f32(p + ".norm2.weight", w.hid_r, w.hid); w.n2b = f32(p + ".norm2.bias", w.hid_r, w.hid);
+    w.w_expand = mat(p + ".expand.weight", w.hid_r, cin_r, &w.w_expand_t, w.hid, w.cin);
     w.w_dw = reserve((size_t)9 * w.hid * 4);
     w.w_dw_flip = reserve((size_t)9 * w.hid * 4);
-    { Param& q = add(p + ".depthwise.weight", (int64_t)w.hid * 9, PK_DW, w.w_dw); q.O = w.hid; set_shape(q, {w.hid, 1, 3, 3});
+    { Param& q = add(p + ".depthwise.weight", (int64_t)w.hid_r * 9, PK_DW, w.w_dw); q.O = w.hid_r; q.Op = w.hid; set_shape(q, {w.hid_r, 1, 3, 3});
       q.has_t = true; q.t_off = w.w_dw_flip; }
-    w.se_w1 = mat(p + ".se.fc1.weight", w.sq, w.hid); w.se_b1 = f32(p + ".se.fc1.bias", w.sq);
-    w.se_w2 = mat(p + ".se.fc2.weight", w.hid, w.sq); w.se_b2 = f32(p + ".se.fc2.bias", w.hid);
-    const int kp = w.hid + (w.skip ? cin : 0);  // project and skip share one K-concatenated matrix
-    w.w_proj = reserve((size_t)cout * kp * es());
-    w.w_proj_t = reserve((size_t)cout * kp * es());  // [kp][cout]: project rows first, then the skip rows
-    mat_into(p + ".project.weight", cout, w.hid, w.w_proj, kp, 0);
+    w.se_w1 = mat(p + ".se.fc1.weight", w.sq, w.hid_r, nullptr, w.sq, w.hid); w.se_b1 = f32(p + ".se.fc1.bias", w.sq);
+    w.se_w2 = mat(p + ".se.fc2.weight", w.hid_r, w.sq, nullptr, w.hid, w.sq); w.se_b2 = f32(p + ".se.fc2.bias", w.hid_r, w.hid);
+    const int kp = w.hid + (w.skip ? w.cin : 0);  // project and skip share one K-concatenated matrix
+    w.w_proj = reserve((size_t)w.cout * kp * es());
+    w.w_proj_t = reserve((size_t)w.cout * kp * es());  // [kp][cout]: project rows first, then the skip rows
+    mat_into(p + ".project.weight", cout_r, w.hid_r, w.w_proj, kp, 0);
     c->params.back().has_t = true; c->params.back().t_off = w.w_proj_t;
     // FiLM Linear: rows appended to the global [F][T] fp32 table (filled in finish())
     w.film_off = c->film_rows;
-    c->film_rows += 2 * w.hid;
-    film_keys.push_back({p + ".time_mlp.1", 2 * w.hid, w.film_off});
-    if (w.skip) pending_skip.push_back({p + ".skip.weight", cout, cin, w.w_proj, kp, w.hid, w.w_proj_t + (size_t)w.hid * cout * es()});
+    c->film_rows += 2 * w.hid_r;
+    film_keys.push_back({p + ".time_mlp.1", 2 * w.hid_r, w.film_off});
+    if (w.skip) pending_skip.push_back({p + ".skip.weight", cout_r, cin_r, w.w_proj, kp, w.hid, w.w_proj_t + (size_t)w.hid * w.cout * es()});
     flush_pending();  // registration order: ... project, time_mlp, skip
     c->irbs.push_back(w);
     return (int)c->irbs.size() - 1;
   }
+  bool bad = false;
   struct FilmKey { std::string p; int rows, off; };
   struct SkipKey { std::string key; int rows, cols; size_t off; int ld, col0; size_t t_off; };
   std::vector<FilmKey> film_keys;
@@ -298,6 +325,7 @@ struct Builder {
     pending_skip.clear();
   }
   int add_attn(const std::string& p, int ch, int heads) {
+    if (ch % 32) bad = true;
     AttnW w{};
     w.c = ch; w.heads = heads; w.inner = heads * 32;
     w.p_first = (int)c->params.size();
@@ -308,15 +336,17 @@ struct Builder {
     c->attns.push_back(w);
     return (int)c->attns.size() - 1;
   }
-  ConvW add_conv3(const std::string& p, int ch) {
+  ConvW add_conv3(const std::string& p, int ch_r) {
     ConvW w{};
-    w.c = ch;
+    const int ch = pad32(ch_r);
+    if (ch != ch_r) c->padded = true;
+    w.c = ch; w.c_r = ch_r;
     w.p_first = (int)c->params.size();
     w.w = reserve((size_t)9 * ch * ch * es());
     w.w_t = reserve((size_t)9 * ch * ch * es());
-    { Param& q = add(p + ".weight", (int64_t)ch * ch * 9, PK_CONV3, w.w); q.O = ch; q.I = ch; set_shape(q, {ch, ch, 3, 3});
-      q.has_t = true; q.t_off = w.w_t; }
-    w.bias = f32(p + ".bias", ch);
+    { Param& q = add(p + ".weight", (int64_t)ch_r * ch_r * 9, PK_CONV3, w.w); q.O = ch_r; q.I = ch_r; q.Op = ch; q.Ip = ch;
+      set_shape(q, {ch_r, ch_r, 3, 3}); q.has_t = true; q.t_off = w.w_t; }
+    w.bias = f32(p + ".bias", ch_r, ch);
     return w;
   }
   void finish_film() {
@@ -342,12 +372,22 @@ int build_unet(llie_ctx* c) {
   const llie_config& g = c->cfg;
   Builder b{c};
   c->channels.clear();
-  for (int i = 0; i < 4; ++i) c->channels.push_back(g.base_channels * g.channel_multipliers[i]);
-  const std::vector<int>& ch = c->channels;
+  c->channels_r.clear();
+  for (int i = 0; i < 4; ++i) {
+    c->channels_r.push_back(g.base_channels * g.channel_multipliers[i]);
+    c->channels.push_back(pad32(c->channels_r.back()));
+  }
+  const std::vector<int>& ch = c->channels_r;  // the builder registers parameters with the reference's shapes
   const int T = g.time_embed_dim, e = g.expansion_ratio;
-  // GroupNorm(min(32,C), C) must be constructible for every site (efficient_unet.py:170-171,263,528)
+  // GroupNorm(min(32,C), C) must be constructible for every site (efficient_unet.py:170-171,263,528) -- unless the
+  // caller opted into the unpinned variants (allow_unpinned: groups = largest divisor <= 32, channels zero-padded)
   auto gn_ok = [](int x) { return x >= 32 && x % 32 == 0; };
-  {
+  if (g.allow_unpinned) {
+    // what the padding scheme needs: the first segment of every virtual concat and every attention input unpadded
+    for (int l = 1; l < 4; ++l)
+      if (ch[l] % 32) return LLIE_ERR_CONFIG;
+    if (g.base_channels < 8 || g.base_channels % 8) return LLIE_ERR_CONFIG;
+  } else {
     int in_ch = ch[0];
     for (int l = 0; l < 4; ++l) {
       for (int k = 0; k < g.num_res_blocks; ++k) {
@@ -371,10 +411,12 @@ int build_unet(llie_ctx* c) {
   c->t_w3 = b.f32("time_mlp.3.weight", (int64_t)T * T);
   Builder::set_shape(c->params.back(), {T, T});
   c->t_b3 = b.f32("time_mlp.3.bias", T);
-  c->init_w = b.reserve((size_t)ch[0] * g.in_channels * 9 * 4);
-  { Param& p = b.add("init_conv.weight", (int64_t)ch[0] * g.in_channels * 9, PK_INIT, c->init_w); p.O = ch[0]; p.I = g.in_channels; Builder::set_shape(p, {ch[0], g.in_channels, 3, 3}); }
-  c->init_b = b.f32("init_conv.bias", ch[0]);
-  c->init_wp = b.reserve((size_t)10 * ch[0] * 8 * 2);
+  const int c0p = c->channels[0];
+  if (c0p != ch[0]) c->padded = true;
+  c->init_w = b.reserve((size_t)c0p * g.in_channels * 9 * 4);
+  { Param& p = b.add("init_conv.weight", (int64_t)ch[0] * g.in_channels * 9, PK_INIT, c->init_w); p.O = ch[0]; p.I = g.in_channels; p.Op = c0p; Builder::set_shape(p, {ch[0], g.in_channels, 3, 3}); }
+  c->init_b = b.f32("init_conv.bias", ch[0], c0p);
+  c->init_wp = b.reserve((size_t)10 * c0p * 8 * 2);
 
   int res = g.image_size;
   auto is_attn_res = [&](int r) { return r == g.attention_resolutions[0] || r == g.attention_resolutions[1]; };
@@ -403,7 +445,7 @@ int build_unet(llie_ctx* c) {
     int k = 0;
     for (int r = 0; r < g.num_res_blocks + 1; ++r) {
       const std::string p = "decoder_blocks." + std::to_string(l) + "." + std::to_string(k++);
-      c->dec[l].push_back({0, b.add_irb(p, r == 0 ? in_ch + out : out, out, T, e)});
+      c->dec[l].push_back({0, b.add_irb(p, r == 0 ? in_ch + out : out, out, T, e, r == 0 ? in_ch : 0)});
       if (is_attn_res(res)) {
         const std::string pa = "decoder_blocks." + std::to_string(l) + "." + std::to_string(k++);
         c->dec[l].push_back({1, b.add_attn(pa, out, g.num_attention_heads)});
@@ -413,16 +455,17 @@ int build_unet(llie_ctx* c) {
     if (l < 3) res *= 2;
   }
   for (int l = 0; l < 3; ++l) c->ups.push_back(b.add_conv3("upsamplers." + std::to_string(l) + ".conv", ch[3 - l]));
-  c->fin_g = b.f32("final_norm.weight", ch[0]);
-  c->fin_b = b.f32("final_norm.bias", ch[0]);
-  c->fin_w = b.reserve((size_t)9 * ch[0] * 4 * 4);
-  { Param& p = b.add("final_conv.weight", (int64_t)g.out_channels * ch[0] * 9, PK_FINAL, c->fin_w); p.O = g.out_channels; p.I = ch[0]; Builder::set_shape(p, {g.out_channels, ch[0], 3, 3}); }
+  c->fin_g = b.f32("final_norm.weight", ch[0], c0p);
+  c->fin_b = b.f32("final_norm.bias", ch[0], c0p);
+  c->fin_w = b.reserve((size_t)9 * c0p * 4 * 4);
+  { Param& p = b.add("final_conv.weight", (int64_t)g.out_channels * ch[0] * 9, PK_FINAL, c->fin_w); p.O = g.out_channels; p.I = ch[0]; p.Ip = c0p; Builder::set_shape(p, {g.out_channels, ch[0], 3, 3}); }
   c->fin_bias = b.f32("final_conv.bias", g.out_channels);
-  c->fin_wp = b.reserve((size_t)(ch[0] / 32) * 18 * 2 * 4 * 8 * 2);
+  c->fin_wp = b.reserve((size_t)(c0p / 32) * 18 * 2 * 4 * 8 * 2);
   c->freqs = b.reserve((size_t)(g.base_channels / 2) * 4);
   b.finish_film();
   c->blob_bytes = b.cursor;
   assign_grad_offsets(c);
+  if (b.bad) return LLIE_ERR_CONFIG;
   return LLIE_OK;
 }
 
@@ -433,7 +476,7 @@ int build_module(llie_ctx* c) {
   switch (g.kind) {
     case LLIE_IRB:
       if (!gn_ok(g.in_channels) || !gn_ok(g.in_channels * g.expansion_ratio) || g.out_channels % 32) return LLIE_ERR_CONFIG;
-      b.add_irb("", g.in_channels, g.out_channels, g.time_embed_dim, g.expansion_ratio);
+      b.add_irb("", g.in_channels, g.out_channels, g.time_embed_dim, g.expansion_ratio, g.base_channels);
       // keys of a bare block have no leading dot
       break;
     case LLIE_ATTN:
@@ -493,9 +536,10 @@ struct Run {
     c->prof.push_back(r);
   }
 
-  Tens new_tens(int C, int H, int W, int ntiles) {
+  Tens new_tens(int C, int H, int W, int ntiles, int Cr = 0) {
     Tens t;
     t.C = C; t.H = H; t.W = W; t.ntiles = ntiles; t.valid = true;
+    t.Cr = Cr > 0 ? Cr : C;
     t.off = ar->alloc((size_t)B * H * W * C * es());
     t.slab = ar->alloc((size_t)B * ntiles * 2 * C * 4);
     return t;
@@ -512,6 +556,7 @@ struct Run {
   void gn(const Tens& x0, const Tens* x1, size_t gamma, size_t beta, const float* film, int64_t film_stride,
           size_t& as, size_t& ab, GnRec* rec = nullptr) {
     const int C = x0.C + (x1 ? x1->C : 0);
+    const int Creal = x0.Cr + (x1 ? x1->Cr : 0);  // x0 is unpadded whenever x1 exists (checked at build time)
     as = ar->alloc((size_t)B * C * 4);
     ab = ar->alloc((size_t)B * C * 4);
     size_t mo = 0, ro = 0;
@@ -524,7 +569,7 @@ struct Run {
     GnFinalizeArgs a{};
     a.src[0] = src(x0);
     if (x1) a.src[1] = src(*x1);
-    a.C = C; a.groups = 32; a.P = x0.H * x0.W;
+    a.C = C; a.Creal = Creal; a.groups = gn_groups(Creal); a.P = x0.H * x0.W;
     a.gamma = wptr<float>(gamma); a.beta = wptr<float>(beta);
     a.film = film; a.film_stride = film_stride; a.eps = 1e-5f;
     a.as = p<float>(as); a.ab = p<float>(ab); a.B = B;
@@ -544,7 +589,7 @@ struct Run {
     const bool fused = !tape && g_use_dwx && dwx_supported(dt, w.cin, w.hid, H, W);
     // K1: expand with norm1 + ReLU6 prologue
     Tens h1;
-    h1.C = w.hid; h1.H = H; h1.W = W; h1.ntiles = P / BM; h1.valid = true;
+    h1.C = w.hid; h1.Cr = w.hid_r; h1.H = H; h1.W = W; h1.ntiles = P / BM; h1.valid = true;
     h1.off = fused ? 0 : ar->alloc((size_t)B * P * w.hid * es());
     h1.slab = ar->alloc((size_t)B * h1.ntiles * 2 * w.hid * 4);
     if (!dry) {
@@ -601,7 +646,7 @@ struct Run {
     }
     rel(pool); rel(sehid); rel(semean);
     // K3: project with SE gate prologue (+ skip conv as extra K segments, or identity residual)
-    Tens y = new_tens(w.cout, H, W, P / BM);
+    Tens y = new_tens(w.cout, H, W, P / BM, w.cout_r);
     if (!dry) {
       GemmArgs g{};
       g.seg[0] = GemmSeg{p(h2), w.hid, p<float>(gate), nullptr, w.hid, ACT_NONE};
@@ -688,7 +733,7 @@ struct Run {
 
   Tens conv3(const ConvW& w, const Tens& x, int mode) {
     const int Ho = mode == 0 ? x.H / 2 : x.H * 2, Wo = mode == 0 ? x.W / 2 : x.W * 2;
-    Tens y = new_tens(w.c, Ho, Wo, conv3x3_ntiles(Ho, Wo));
+    Tens y = new_tens(w.c, Ho, Wo, conv3x3_ntiles(Ho, Wo), w.c_r);
     Tens u;
     if (tape && mode == 1) {
       // training: keep the upsampled tensor (the weight gradient reads it) and run the plain stride-1 conv on it
@@ -753,7 +798,7 @@ struct Run {
     const float* filmp = p<float>(film);
     const int64_t fstride = uniform_t ? 0 : F;
 
-    Tens h = new_tens(c->channels[0], S, S, init_conv_ntiles(S, S));
+    Tens h = new_tens(c->channels[0], S, S, init_conv_ntiles(S, S), c->channels_r[0]);
     if (!dry) {
       InitConvArgs a{};
       const int half = g.in_channels / 2;
@@ -1397,23 +1442,24 @@ int llie_load_param(llie_ctx* c, const char* key, const float* src, int64_t nume
     case PK_F32: e = hipMemcpyAsync(dst, src, (size_t)numel * 4, hipMemcpyDeviceToDevice, s); break;
     case PK_MAT:
       e = launch_cvt_rows(p.as_t ? c->dt : 0, src, dst, p.rows, p.cols, p.ld, p.col0, s);
-      if (e == hipSuccess && p.has_t) e = launch_cvt_rows_t(c->dt, src, c->blob + p.t_off, p.rows, p.cols, s);
+      // transposed copies feed the backward pass, which the padded (unpinned) variants do not have
+      if (e == hipSuccess && p.has_t && !c->padded) e = launch_cvt_rows_t(c->dt, src, c->blob + p.t_off, p.rows, p.cols, s);
       break;
     case PK_CONV3:
-      e = launch_repack_conv3x3(c->dt, src, dst, p.O, p.I, s);
-      if (e == hipSuccess && p.has_t) e = launch_repack_conv3x3_t(c->dt, src, c->blob + p.t_off, p.O, p.I, s);
+      e = launch_repack_conv3x3(c->dt, src, dst, p.O, p.I, s, p.Op, p.Ip);
+      if (e == hipSuccess && p.has_t && !c->padded) e = launch_repack_conv3x3_t(c->dt, src, c->blob + p.t_off, p.O, p.I, s);
       break;
     case PK_DW:
-      e = launch_repack_dw(src, reinterpret_cast<float*>(dst), p.O, s);
-      if (e == hipSuccess && p.has_t) e = launch_repack_dw_flip(src, reinterpret_cast<float*>(c->blob + p.t_off), p.O, s);
+      e = launch_repack_dw(src, reinterpret_cast<float*>(dst), p.O, s, p.Op);
+      if (e == hipSuccess && p.has_t) e = launch_repack_dw_flip(src, reinterpret_cast<float*>(c->blob + p.t_off), p.O, s, p.Op);
       break;
     case PK_INIT:
-      e = launch_repack_init(src, reinterpret_cast<float*>(dst), p.O, p.I, s);
-      if (e == hipSuccess && c->dt != LLIE_F32) e = launch_repack_init_mfma(c->dt, src, c->blob + c->init_wp, p.O, p.I, s);
+      e = launch_repack_init(src, reinterpret_cast<float*>(dst), p.O, p.I, s, p.Op);
+      if (e == hipSuccess && c->dt != LLIE_F32) e = launch_repack_init_mfma(c->dt, src, c->blob + c->init_wp, p.O, p.I, s, p.Op);
       break;
     case PK_FINAL:
-      e = launch_repack_final(src, reinterpret_cast<float*>(dst), p.O, p.I, s);
-      if (e == hipSuccess && c->dt != LLIE_F32) e = launch_repack_final_mfma(c->dt, src, c->blob + c->fin_wp, p.O, p.I, s);
+      e = launch_repack_final(src, reinterpret_cast<float*>(dst), p.O, p.I, s, p.Ip);
+      if (e == hipSuccess && c->dt != LLIE_F32) e = launch_repack_final_mfma(c->dt, src, c->blob + c->fin_wp, p.O, p.I, s, p.Ip);
       break;
   }
   if (e != hipSuccess) { set_err("repack of '%s' failed: %s", key, hipGetErrorString(e)); return (int)e; }
@@ -1443,6 +1489,8 @@ int llie_load_all(llie_ctx* c, const float* const* srcs, int n, llie_stream stre
       LoadDesc e{};
       e.src = srcs[i]; e.numel = p.numel; e.dst = (long long)p.off; e.dst_t = p.has_t ? (long long)p.t_off : -1;
       e.as_t = p.as_t ? 1 : 0; e.rows = p.rows; e.cols = p.cols; e.ld = p.ld; e.col0 = p.col0; e.O = p.O; e.I = p.I;
+      e.Op = p.Op > 0 ? p.Op : p.O; e.Ip = p.Ip > 0 ? p.Ip : p.I;
+      if (c->padded && p.kind != PK_DW) e.dst_t = -1;  // no backward pass for the padded variants (see llie_load_param)
       e.kind = p.kind == PK_F32 ? 0 : (p.kind == PK_MAT ? 1 : (p.kind == PK_CONV3 ? 2 : 3));
       d.push_back(e);
     }
@@ -1559,6 +1607,7 @@ int64_t llie_param_grad_offset(const llie_ctx* c, int i) {
 
 int64_t llie_train_workspace_bytes(llie_ctx* c, int batch, int height, int width) {
   if (!c || batch <= 0) return LLIE_ERR_ARG;
+  if (c->padded) { set_err("the unpinned variants (tiny / base, zero-padded channels) are inference-only"); return LLIE_ERR_CONFIG; }
   Arena ar((size_t)1 << 46);
   Tape tape;
   Run r{c, &ar, nullptr, nullptr, true, batch, c->dt};
@@ -1579,6 +1628,7 @@ int64_t llie_train_workspace_bytes(llie_ctx* c, int batch, int height, int width
 int llie_unet_train_forward(llie_ctx* c, const float* lat, const float* cond, const int64_t* t, float* eps, int batch,
                             void* ws, int64_t ws_bytes, llie_stream stream) {
   if (!c || !lat || !cond || !t || !eps || !ws || batch <= 0 || c->cfg.kind != LLIE_UNET) return LLIE_ERR_ARG;
+  if (c->padded) { set_err("the unpinned variants (tiny / base, zero-padded channels) are inference-only"); return LLIE_ERR_CONFIG; }
   if (!c->blob) { set_err("no HIP device"); return LLIE_ERR_NO_DEVICE; }
   int rc = check_loaded(c);
   if (rc) return rc;

@@ -74,6 +74,7 @@ struct GnFinalizeArgs {
   float* as;         // [B][C]
   float* ab;         // [B][C]
   int B;
+  int Creal;         // 0 = C; otherwise the groups partition channels [0, Creal) and the rest (zero padding) gets a zero affine
   float* mean_out;   // optional [B][groups] (training: kept for the backward pass)
   float* rstd_out;
 };
@@ -219,13 +220,14 @@ hipError_t launch_nhwc_to_nchw(int dtype, const void* x, float* y, int B, int C,
 // Weight repack at load time (fp32 reference layout -> engine layout).
 hipError_t launch_cvt_rows(int dtype, const float* src, void* dst, int rows, int cols, int dst_ld, int dst_col0,
                            hipStream_t s);                       // dst[r*ld + col0 + c] = T(src[r*cols + c])
-hipError_t launch_repack_conv3x3(int dtype, const float* src, void* dst, int Cout, int Cin, hipStream_t s);  // OIHW -> [9][O][I]
-hipError_t launch_repack_dw(const float* src, float* dst, int C, hipStream_t s);                             // [C][1][3][3] -> [9][C]
-hipError_t launch_repack_dw_flip(const float* src, float* dst, int C, hipStream_t s);                        // [C][1][3][3] -> [8-tap][C]
-hipError_t launch_repack_init(const float* src, float* dst, int O, int I, hipStream_t s);                    // OIHW -> [I*9][O]
-hipError_t launch_repack_final(const float* src, float* dst, int O, int I, hipStream_t s);                   // OIHW -> [9][I][4]
-hipError_t launch_repack_final_mfma(int dtype, const float* src, void* dst, int O, int I, hipStream_t s);    // OIHW -> [I/32][18][2][4][8] T
-hipError_t launch_repack_init_mfma(int dtype, const float* src, void* dst, int O, int I, hipStream_t s);     // OIHW -> [5][2][O][8] T
+hipError_t launch_repack_conv3x3(int dtype, const float* src, void* dst, int Cout, int Cin, hipStream_t s, int Op = 0,
+                                 int Ip = 0);  // OIHW -> [9][Op][Ip] (Op, Ip: padded destination dims, 0 = unpadded)
+hipError_t launch_repack_dw(const float* src, float* dst, int C, hipStream_t s, int Cp = 0);                 // [C][1][3][3] -> [9][Cp]
+hipError_t launch_repack_dw_flip(const float* src, float* dst, int C, hipStream_t s, int Cp = 0);            // [C][1][3][3] -> [8-tap][Cp]
+hipError_t launch_repack_init(const float* src, float* dst, int O, int I, hipStream_t s, int Op = 0);        // OIHW -> [I*9][Op]
+hipError_t launch_repack_final(const float* src, float* dst, int O, int I, hipStream_t s, int Ip = 0);       // OIHW -> [9][Ip][4]
+hipError_t launch_repack_final_mfma(int dtype, const float* src, void* dst, int O, int I, hipStream_t s, int Ip = 0);  // OIHW -> [Ip/32][18][2][4][8] T
+hipError_t launch_repack_init_mfma(int dtype, const float* src, void* dst, int O, int I, hipStream_t s, int Op = 0);   // OIHW -> [5][2][Op][8] T
 
 // All plain / matrix / 3x3 / depthwise parameters in ONE launch (an optimiser step changes every parameter: 300+
 // small repack launches would cost more than the repack itself).  Offsets are bytes into the weight blob; -1 = none.
@@ -233,7 +235,7 @@ struct LoadDesc {
   const float* src;
   int kind;            // 0 fp32 copy, 1 matrix (cvt_rows [+ transposed copy]), 2 OIHW 3x3 ([tap][O][I] [+ [8-tap][I][O]]), 3 depthwise ([tap][C] + flipped)
   int as_t;            // matrix: destination in the compute dtype (1) or fp32 (0)
-  int rows, cols, ld, col0, O, I;
+  int rows, cols, ld, col0, O, I, Op, Ip;  // Op / Ip: padded destination dims of the 3x3 / depthwise layouts
   long long numel, dst, dst_t;
 };
 hipError_t launch_load_all(int dtype, const LoadDesc* descs_dev, int n, char* blob, hipStream_t s);

@@ -19,8 +19,16 @@ const char* last_kernel() { return g_last_kernel; }
 __global__ void __launch_bounds__(256) gn_finalize_kernel(const GnFinalizeArgs a) {
   __shared__ double part[2][4];
   const int g = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int cg = a.C / a.groups;
+  // groups partition the REAL channels [0, Creal); channels beyond (zero padding of the unpinned variants, always
+  // at the end of the tensor / of the second concat segment) get a zero affine so they stay zero
+  const int Creal = a.Creal > 0 ? a.Creal : a.C;
+  const int cg = Creal / a.groups;
   const int c_lo = g * cg;
+  if (g == 0)
+    for (int c = Creal + tid; c < a.C; c += 256) {
+      a.as[(size_t)b * a.C + c] = 0.f;
+      a.ab[(size_t)b * a.C + c] = 0.f;
+    }
   double s1 = 0.0, s2 = 0.0;
   int coff = 0;
   for (int s = 0; s < 2; ++s) {
@@ -76,7 +84,7 @@ __global__ void __launch_bounds__(256) gn_finalize_kernel(const GnFinalizeArgs a
     float sc = ga, sh = a.beta[c] - fmean * ga;
     if (a.film) {
       const float* f = a.film + (size_t)b * a.film_stride;
-      const float fs = 1.f + f[c], fh = f[a.C + c];
+      const float fs = 1.f + f[c], fh = f[Creal + c];
       sc *= fs;
       sh = sh * fs + fh;
     }
@@ -86,7 +94,7 @@ __global__ void __launch_bounds__(256) gn_finalize_kernel(const GnFinalizeArgs a
 }
 
 hipError_t launch_gn_finalize(const GnFinalizeArgs& a, hipStream_t s) {
-  if (a.C % a.groups || a.groups <= 0) return hipErrorInvalidValue;
+  if ((a.Creal > 0 ? a.Creal : a.C) % a.groups || a.groups <= 0 || a.Creal > a.C) return hipErrorInvalidValue;
   int c = 0;
   for (int i = 0; i < 2; ++i)
     if (a.src[i].slab) c += a.src[i].ch;
@@ -579,43 +587,47 @@ hipError_t launch_cvt_rows(int dtype, const float* src, void* dst, int rows, int
 }
 // OIHW [O][I][3][3] -> [tap][O][I]
 template <typename T>
-__global__ void repack_conv3x3_kernel(const float* src, T* dst, int O, int I) {
+__global__ void repack_conv3x3_kernel(const float* src, T* dst, int O, int I, int Op, int Ip) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (int64_t)O * I * 9) return;
   const int tap = (int)(i % 9);
   const int ci = (int)((i / 9) % I), co = (int)(i / (9 * (int64_t)I));
-  dst[((size_t)tap * O + co) * I + ci] = (T)src[i];
+  dst[((size_t)tap * Op + co) * Ip + ci] = (T)src[i];
 }
-hipError_t launch_repack_conv3x3(int dtype, const float* src, void* dst, int O, int I, hipStream_t s) {
+hipError_t launch_repack_conv3x3(int dtype, const float* src, void* dst, int O, int I, hipStream_t s, int Op, int Ip) {
+  if (Op <= 0) Op = O;
+  if (Ip <= 0) Ip = I;
   const int64_t n = (int64_t)O * I * 9;
   dim3 grid((unsigned)((n + 255) / 256));
   switch (dtype) {
-    case 0: hipLaunchKernelGGL(repack_conv3x3_kernel<float>, grid, dim3(256), 0, s, src, (float*)dst, O, I); break;
-    case 1: hipLaunchKernelGGL(repack_conv3x3_kernel<half_t>, grid, dim3(256), 0, s, src, (half_t*)dst, O, I); break;
-    case 2: hipLaunchKernelGGL(repack_conv3x3_kernel<bf16_t>, grid, dim3(256), 0, s, src, (bf16_t*)dst, O, I); break;
+    case 0: hipLaunchKernelGGL(repack_conv3x3_kernel<float>, grid, dim3(256), 0, s, src, (float*)dst, O, I, Op, Ip); break;
+    case 1: hipLaunchKernelGGL(repack_conv3x3_kernel<half_t>, grid, dim3(256), 0, s, src, (half_t*)dst, O, I, Op, Ip); break;
+    case 2: hipLaunchKernelGGL(repack_conv3x3_kernel<bf16_t>, grid, dim3(256), 0, s, src, (bf16_t*)dst, O, I, Op, Ip); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();
 }
-__global__ void repack_dw_kernel(const float* src, float* dst, int C) {
+__global__ void repack_dw_kernel(const float* src, float* dst, int C, int Cp) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= C * 9) return;
   const int tap = i % 9, c = i / 9;
-  dst[tap * C + c] = src[i];
+  dst[tap * Cp + c] = src[i];
 }
-hipError_t launch_repack_dw(const float* src, float* dst, int C, hipStream_t s) {
-  hipLaunchKernelGGL(repack_dw_kernel, dim3((C * 9 + 255) / 256), dim3(256), 0, s, src, dst, C);
+hipError_t launch_repack_dw(const float* src, float* dst, int C, hipStream_t s, int Cp) {
+  if (Cp <= 0) Cp = C;
+  hipLaunchKernelGGL(repack_dw_kernel, dim3((C * 9 + 255) / 256), dim3(256), 0, s, src, dst, C, Cp);
   return hipGetLastError();
 }
 // taps flipped: the input-gradient of a depthwise conv is the same conv with w'[t] = w[8 - t]
-__global__ void repack_dw_flip_kernel(const float* src, float* dst, int C) {
+__global__ void repack_dw_flip_kernel(const float* src, float* dst, int C, int Cp) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= C * 9) return;
   const int tap = i % 9, c = i / 9;
-  dst[(8 - tap) * C + c] = src[i];
+  dst[(8 - tap) * Cp + c] = src[i];
 }
-hipError_t launch_repack_dw_flip(const float* src, float* dst, int C, hipStream_t s) {
-  hipLaunchKernelGGL(repack_dw_flip_kernel, dim3((C * 9 + 255) / 256), dim3(256), 0, s, src, dst, C);
+hipError_t launch_repack_dw_flip(const float* src, float* dst, int C, hipStream_t s, int Cp) {
+  if (Cp <= 0) Cp = C;
+  hipLaunchKernelGGL(repack_dw_flip_kernel, dim3((C * 9 + 255) / 256), dim3(256), 0, s, src, dst, C, Cp);
   return hipGetLastError();
 }
 
@@ -636,12 +648,12 @@ __global__ void __launch_bounds__(256) load_all_kernel(const LoadDesc* descs, ch
     } else if (d.kind == 2) {
       const int tap = (int)(i % 9);
       const int ci = (int)((i / 9) % d.I), co = (int)(i / (9 * (long long)d.I));
-      reinterpret_cast<T*>(blob + d.dst)[((size_t)tap * d.O + co) * d.I + ci] = (T)v;
-      if (d.dst_t >= 0) reinterpret_cast<T*>(blob + d.dst_t)[((size_t)(8 - tap) * d.I + ci) * d.O + co] = (T)v;
+      reinterpret_cast<T*>(blob + d.dst)[((size_t)tap * d.Op + co) * d.Ip + ci] = (T)v;
+      if (d.dst_t >= 0) reinterpret_cast<T*>(blob + d.dst_t)[((size_t)(8 - tap) * d.Ip + ci) * d.Op + co] = (T)v;
     } else {
       const int tap = (int)(i % 9), c = (int)(i / 9);
-      reinterpret_cast<float*>(blob + d.dst)[(size_t)tap * d.O + c] = v;
-      if (d.dst_t >= 0) reinterpret_cast<float*>(blob + d.dst_t)[(size_t)(8 - tap) * d.O + c] = v;
+      reinterpret_cast<float*>(blob + d.dst)[(size_t)tap * d.Op + c] = v;
+      if (d.dst_t >= 0) reinterpret_cast<float*>(blob + d.dst_t)[(size_t)(8 - tap) * d.Op + c] = v;
     }
   }
 }
@@ -657,64 +669,68 @@ hipError_t launch_load_all(int dtype, const LoadDesc* descs_dev, int n, char* bl
 }
 
 // init_conv OIHW [O][I][3][3] -> [I*9][O];  final_conv OIHW [O<=4][I][3][3] -> [9][I][4] zero padded
-__global__ void repack_init_kernel(const float* src, float* dst, int O, int I) {
+__global__ void repack_init_kernel(const float* src, float* dst, int O, int I, int Op) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= O * I * 9) return;
   const int k = i % (I * 9), o = i / (I * 9);
-  dst[k * O + o] = src[i];
+  dst[k * Op + o] = src[i];
 }
-hipError_t launch_repack_init(const float* src, float* dst, int O, int I, hipStream_t s) {
-  hipLaunchKernelGGL(repack_init_kernel, dim3((O * I * 9 + 255) / 256), dim3(256), 0, s, src, dst, O, I);
+hipError_t launch_repack_init(const float* src, float* dst, int O, int I, hipStream_t s, int Op) {
+  if (Op <= 0) Op = O;
+  hipLaunchKernelGGL(repack_init_kernel, dim3((O * I * 9 + 255) / 256), dim3(256), 0, s, src, dst, O, I, Op);
   return hipGetLastError();
 }
 // init_conv for the MFMA kernel: dst[((s*2+h)*O + n)*8 + ci] = W[n][ci][tap = 2s+h] (zero when tap > 8 or ci >= I)
 template <typename T>
-__global__ void repack_init_mfma_kernel(const float* src, T* dst, int O, int I) {
+__global__ void repack_init_mfma_kernel(const float* src, T* dst, int O, int I, int Op) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= 10 * O * 8) return;
-  const int ci = i & 7, n = (i >> 3) % O, tap = (i >> 3) / O;
-  dst[i] = (tap < 9 && ci < I) ? (T)src[((size_t)n * I + ci) * 9 + tap] : (T)0.f;
+  if (i >= 10 * Op * 8) return;
+  const int ci = i & 7, n = (i >> 3) % Op, tap = (i >> 3) / Op;
+  dst[i] = (tap < 9 && ci < I && n < O) ? (T)src[((size_t)n * I + ci) * 9 + tap] : (T)0.f;
 }
-hipError_t launch_repack_init_mfma(int dtype, const float* src, void* dst, int O, int I, hipStream_t s) {
+hipError_t launch_repack_init_mfma(int dtype, const float* src, void* dst, int O, int I, hipStream_t s, int Op) {
   if (I > 8) return hipErrorInvalidValue;
-  dim3 grid((10 * O * 8 + 255) / 256);
+  if (Op <= 0) Op = O;
+  dim3 grid((10 * Op * 8 + 255) / 256);
   switch (dtype) {
-    case 1: hipLaunchKernelGGL(repack_init_mfma_kernel<half_t>, grid, dim3(256), 0, s, src, (half_t*)dst, O, I); break;
-    case 2: hipLaunchKernelGGL(repack_init_mfma_kernel<bf16_t>, grid, dim3(256), 0, s, src, (bf16_t*)dst, O, I); break;
+    case 1: hipLaunchKernelGGL(repack_init_mfma_kernel<half_t>, grid, dim3(256), 0, s, src, (half_t*)dst, O, I, Op); break;
+    case 2: hipLaunchKernelGGL(repack_init_mfma_kernel<bf16_t>, grid, dim3(256), 0, s, src, (bf16_t*)dst, O, I, Op); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();
 }
 // final_conv for the MFMA kernel: dst[(((chunk*18 + ks)*2 + h)*4 + o)*8 + j] = W[o][chunk*32 + (ks&1)*16 + h*8 + j][tap = ks>>1]
 template <typename T>
-__global__ void repack_final_mfma_kernel(const float* src, T* dst, int O, int I) {
+__global__ void repack_final_mfma_kernel(const float* src, T* dst, int O, int I, int Ip) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  const int total = (I / 32) * 18 * 2 * 4 * 8;
+  const int total = (Ip / 32) * 18 * 2 * 4 * 8;
   if (i >= total) return;
   const int j = i & 7, o = (i >> 3) & 3, h = (i >> 5) & 1, ks = (i >> 6) % 18, chunk = (i >> 6) / 18;
   const int ci = chunk * 32 + (ks & 1) * 16 + h * 8 + j, tap = ks >> 1;
-  dst[i] = o < O ? (T)src[((size_t)o * I + ci) * 9 + tap] : (T)0.f;
+  dst[i] = (o < O && ci < I) ? (T)src[((size_t)o * I + ci) * 9 + tap] : (T)0.f;
 }
-hipError_t launch_repack_final_mfma(int dtype, const float* src, void* dst, int O, int I, hipStream_t s) {
-  if (O > 4 || I % 32) return hipErrorInvalidValue;
-  const int total = (I / 32) * 18 * 2 * 4 * 8;
+hipError_t launch_repack_final_mfma(int dtype, const float* src, void* dst, int O, int I, hipStream_t s, int Ip) {
+  if (Ip <= 0) Ip = I;
+  if (O > 4 || Ip % 32) return hipErrorInvalidValue;
+  const int total = (Ip / 32) * 18 * 2 * 4 * 8;
   dim3 grid((total + 255) / 256);
   switch (dtype) {
-    case 1: hipLaunchKernelGGL(repack_final_mfma_kernel<half_t>, grid, dim3(256), 0, s, src, (half_t*)dst, O, I); break;
-    case 2: hipLaunchKernelGGL(repack_final_mfma_kernel<bf16_t>, grid, dim3(256), 0, s, src, (bf16_t*)dst, O, I); break;
+    case 1: hipLaunchKernelGGL(repack_final_mfma_kernel<half_t>, grid, dim3(256), 0, s, src, (half_t*)dst, O, I, Ip); break;
+    case 2: hipLaunchKernelGGL(repack_final_mfma_kernel<bf16_t>, grid, dim3(256), 0, s, src, (bf16_t*)dst, O, I, Ip); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();
 }
-__global__ void repack_final_kernel(const float* src, float* dst, int O, int I) {
+__global__ void repack_final_kernel(const float* src, float* dst, int O, int I, int Ip) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= 9 * I * 4) return;
-  const int o = i & 3, ci = (i >> 2) % I, tap = (i >> 2) / I;
-  dst[i] = o < O ? src[((size_t)o * I + ci) * 9 + tap] : 0.f;
+  if (i >= 9 * Ip * 4) return;
+  const int o = i & 3, ci = (i >> 2) % Ip, tap = (i >> 2) / Ip;
+  dst[i] = (o < O && ci < I) ? src[((size_t)o * I + ci) * 9 + tap] : 0.f;
 }
-hipError_t launch_repack_final(const float* src, float* dst, int O, int I, hipStream_t s) {
+hipError_t launch_repack_final(const float* src, float* dst, int O, int I, hipStream_t s, int Ip) {
   if (O > 4) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(repack_final_kernel, dim3((9 * I * 4 + 255) / 256), dim3(256), 0, s, src, dst, O, I);
+  if (Ip <= 0) Ip = I;
+  hipLaunchKernelGGL(repack_final_kernel, dim3((9 * Ip * 4 + 255) / 256), dim3(256), 0, s, src, dst, O, I, Ip);
   return hipGetLastError();
 }
 

@@ -29,7 +29,8 @@ class LowLightDiffusionOutput:
 class LowLightDiffusion(nn.Module):
     def __init__(self, unet: Optional[EfficientUNet] = None, scheduler: Optional[LCMScheduler] = None,
                  unet_variant: str = "small", image_size: int = 256, num_inference_steps: int = 4,
-                 condition_mode: str = "concat", compute_dtype: Optional[str] = None):
+                 condition_mode: str = "concat", compute_dtype: Optional[str] = None,
+                 allow_unpinned_groupnorm: bool = False):
         """Arguments as in low_light_diffusion.py:50-58.  `compute_dtype` (extension; "fp32" | "fp16" |
         "bf16") pins the engine precision; when None the engine runs fp32, or the dtype of an active
         `torch.autocast("cuda")` region."""
@@ -42,8 +43,9 @@ class LowLightDiffusion(nn.Module):
         self.num_inference_steps = num_inference_steps
         self.condition_mode = condition_mode
         in_channels = 6
+        extra = {"allow_unpinned_groupnorm": True} if allow_unpinned_groupnorm else {}  # tiny / base: see unet.py
         self.unet = unet if unet is not None else create_efficient_unet(
-            variant=unet_variant, image_size=image_size, in_channels=in_channels)
+            variant=unet_variant, image_size=image_size, in_channels=in_channels, **extra)
         self.scheduler = scheduler if scheduler is not None else LCMScheduler(
             num_train_timesteps=1000, beta_schedule="scaled_linear", prediction_type="epsilon",
             num_inference_steps=num_inference_steps, rescale_betas_zero_snr=True)

@@ -37,6 +37,9 @@ class EfficientUNetConfig:
     dropout: float = 0.0
     quantization_friendly: bool = True
     image_size: int = 256
+    # extension: build topologies whose GroupNorm(min(32, C), C) the reference cannot construct (tiny, base) with
+    # groups = largest divisor of C <= 32.  Nothing can pin their outputs (parity-unpinned); inference only.
+    allow_unpinned_groupnorm: bool = False
 
 
 class _Node(nn.Module):
@@ -350,6 +353,7 @@ class EfficientUNet(_NativeModule):
         c.time_embed_dim, c.num_attention_heads = config.time_embed_dim, config.num_attention_heads
         c.image_size = config.image_size
         c.attention_resolutions[0], c.attention_resolutions[1] = config.attention_resolutions
+        c.allow_unpinned = int(bool(config.allow_unpinned_groupnorm))
         super().__init__(c)
         self.config = config
 
@@ -414,7 +418,8 @@ _VARIANTS = {  # efficient_unet.py:646-687
 
 def create_efficient_unet(variant: str = "small", image_size: int = 256, **kwargs) -> EfficientUNet:
     """efficient_unet.py:631-692.  `tiny` and `base` raise ValueError at construction exactly like the
-    reference (GroupNorm(32, 48))."""
+    reference (GroupNorm(32, 48)) unless `allow_unpinned_groupnorm=True` is passed (an
+    explicitly parity-unpinned deviation, see EfficientUNetConfig)."""
     if variant not in _VARIANTS:
         raise ValueError(f"Unknown variant: {variant}. Choose from {list(_VARIANTS.keys())}")
     cfg = EfficientUNetConfig(channel_multipliers=(1, 2, 4, 8), image_size=image_size, **_VARIANTS[variant], **kwargs)

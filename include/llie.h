@@ -69,6 +69,10 @@ typedef struct llie_config {
   int num_attention_heads;/* UNET, ATTN */
   int image_size;         /* UNET: decides attention placement (efficient_unet.py:426,447,509) */
   int attention_resolutions[2];
+  int allow_unpinned;     /* 0: topologies whose nn.GroupNorm(min(32,C), C) the reference cannot construct (tiny, base)
+                             fail with LLIE_ERR_CONFIG like the reference's ValueError.  1: build them with the
+                             documented deviation groups = largest divisor of C that is <= 32 (no reference output
+                             exists to pin this: parity-unpinned; inference only) */
 } llie_config;
 
 /* LCM scheduler coefficients for one step (host values; computed by the host-side scheduler from the

@@ -27,6 +27,10 @@ class UNetSpec:
     time_embed_dim: int = 128
     image_size: int = 256
     dim_head: int = 32  # LinearAttention default, efficient_unet.py:254
+    # tiny / base cannot be constructed by the reference (GroupNorm(32, 48)).  With allow_unpinned the oracle builds
+    # them with groups = gn_groups(C) below; nothing pins that choice (parity-unpinned), it only gives the engine's
+    # opt-in tiny / base something to be compared with.
+    allow_unpinned: bool = False
 
     @property
     def channels(self) -> List[int]:
@@ -48,9 +52,18 @@ def make_spec(variant: str = "small", image_size: int = 256, in_channels: int = 
     return UNetSpec(in_channels=in_channels, image_size=image_size, **VARIANTS[variant], **kw)
 
 
-def _check_gn(c: int) -> None:
+def gn_groups(c: int) -> int:
+    """min(32, C) wherever nn.GroupNorm accepts it (every constructible variant); otherwise the largest divisor of C
+    that is <= 32 (48 -> 24, 144 -> 24): the unpinned deviation shared with the engine (engine.cpp: gn_groups)."""
     g = min(32, c)
-    if c % g != 0:  # what nn.GroupNorm(min(32, C), C) raises at efficient_unet.py:170 for tiny/base
+    while c % g:
+        g -= 1
+    return g
+
+
+def _check_gn(c: int, allow_unpinned: bool = False) -> None:
+    g = min(32, c)
+    if c % g != 0 and not allow_unpinned:  # what nn.GroupNorm(min(32, C), C) raises at efficient_unet.py:170 for tiny/base
         raise ValueError("num_channels must be divisible by num_groups")
 
 
@@ -97,7 +110,7 @@ def param_shapes(spec: UNetSpec, prefix: str = "unet.") -> "OrderedDict[str, Tup
         out[prefix + k] = tuple(shape)
 
     def gn(k, c):
-        _check_gn(c)
+        _check_gn(c, spec.allow_unpinned)
         put(k + ".weight", c); put(k + ".bias", c)
 
     def irb(p, cin, cout):

@@ -11,7 +11,7 @@ from typing import Dict, List, Optional
 import torch
 import torch.nn.functional as F
 
-from .spec import UNetSpec, block_plan
+from .spec import UNetSpec, block_plan, gn_groups
 
 SD = Dict[str, torch.Tensor]
 
@@ -26,7 +26,8 @@ def sinusoidal_embedding(t: torch.Tensor, dim: int, max_period: float = 10000.0)
 
 def _gn(sd: SD, p: str, x: torch.Tensor) -> torch.Tensor:
     c = x.shape[1]
-    return F.group_norm(x, min(32, c), sd[p + ".weight"], sd[p + ".bias"], eps=1e-5)
+    # gn_groups(c) == min(32, c) for every channel count the reference can construct; see spec.gn_groups
+    return F.group_norm(x, gn_groups(c), sd[p + ".weight"], sd[p + ".bias"], eps=1e-5)
 
 
 def time_embed(sd: SD, spec: UNetSpec, t: torch.Tensor, pre: str) -> torch.Tensor:

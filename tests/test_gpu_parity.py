@@ -463,3 +463,32 @@ def test_non_power_of_two_image_size_192(dev):
     assert max_abs(eps.cpu(), ref) < 1e-3
     out = m.enhance(low.to(dev), 4, noise=torch.stack(noise))
     assert max_abs(out.cpu(), oracle.enhance_ref(sd, spec, low, 4, noise)["enhanced"]) < 1e-3
+
+
+@pytest.mark.parametrize("variant,size,batch", [("base", 64, 2), ("tiny", 64, 2), ("base", 128, 1)])
+def test_unpinned_variants_vs_oracle(dev, variant, size, batch):
+    """tiny / base (opt-in, PARITY-UNPINNED: the reference cannot construct them, so no reference output exists; the
+    oracle applies the same documented GroupNorm deviation, groups = largest divisor of C <= 32).  The engine pads
+    their odd channel counts (16, 48, 144 ...) with zero channels internally; this checks engine == oracle in fp32
+    (one forward and the 4-step loop) and PSNR for fp16."""
+    spec = oracle.make_spec(variant, size, allow_unpinned=True)
+    sd = oracle.synth_state_dict(oracle.param_shapes(spec))
+    m = M.LowLightDiffusion(unet_variant=variant, image_size=size, num_inference_steps=4, allow_unpinned_groupnorm=True)
+    m.load_state_dict(sd)
+    m = m.to(dev).eval()
+    low = torch.rand(batch, 3, size, size, generator=torch.Generator().manual_seed(31)) * 2 - 1
+    noise = oracle.draw_noise(batch, size, 4, seed=32)
+    t = torch.full((batch,), 499, dtype=torch.long)
+    with torch.no_grad():
+        eps = m.unet(torch.cat([noise[0], low], 1).to(dev), t.to(dev))
+    ref = oracle.unet_forward(sd, spec, torch.cat([noise[0], low], 1), t)
+    assert max_abs(eps.cpu(), ref) < 1e-3
+    out = m.enhance(low.to(dev), 4, noise=torch.stack(noise))
+    ref_e = oracle.enhance_ref(sd, spec, low, 4, noise)["enhanced"]
+    assert max_abs(out.cpu(), ref_e) < 1e-3
+    m.compute_dtype = "fp16"
+    assert psnr01(m.enhance(low.to(dev), 4, noise=torch.stack(noise)).cpu(), ref_e) > 40.0
+    with pytest.raises(ValueError):   # inference only
+        m.compute_dtype = None
+        m.train()
+        m.compute_loss(low.to(dev), low.to(dev))

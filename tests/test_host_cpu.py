@@ -14,6 +14,7 @@ import pytest
 import torch
 
 import oracle
+from collections import OrderedDict
 from conftest import GOLDEN, ROOT
 
 M = importlib.import_module("cv-diffusion-model_amd")
@@ -290,3 +291,18 @@ def test_custom_ops_are_registered_with_fake_kernels():
         assert tuple(eps.shape) == (2, 3, 64, 64)
     with pytest.raises((NotImplementedError, RuntimeError)):
         torch.ops.llie.enhance(0, torch.zeros(1, 3, 64, 64), torch.zeros(4, 1, 3, 64, 64), 4)   # CPU tensors: no kernel
+
+
+@pytest.mark.parametrize("variant", ["tiny", "base"])
+def test_unpinned_variants_are_opt_in_and_keep_reference_shapes(variant):
+    """tiny / base: ValueError by default like the reference; with allow_unpinned_groupnorm=True the model is built
+    with the reference's parameter names and shapes (channel padding is internal to the engine)."""
+    with pytest.raises(ValueError):
+        M.create_efficient_unet(variant, image_size=64, in_channels=6)
+    u = M.create_efficient_unet(variant, image_size=64, in_channels=6, allow_unpinned_groupnorm=True)
+    spec = oracle.make_spec(variant, 64, allow_unpinned=True)
+    want = oracle.param_shapes(spec, prefix="")
+    got = OrderedDict((k, tuple(v.shape)) for k, v in u.state_dict().items())
+    assert list(got.items()) == list(want.items())
+    m = M.LowLightDiffusion(unet_variant=variant, image_size=64, allow_unpinned_groupnorm=True)
+    assert len(m.state_dict()) == len(want)
