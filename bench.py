@@ -172,7 +172,8 @@ def main() -> None:
         return
     model = M.LowLightDiffusion(unet_variant=args.variant, image_size=args.image_size,
                                 num_inference_steps=args.lcm_steps, compute_dtype=args.dtype,
-                                allow_unpinned_groupnorm=args.variant in ("tiny", "base"))  # opt-in, parity-unpinned.to(dev).eval()
+                                allow_unpinned_groupnorm=args.variant in ("tiny", "base"))  # opt-in, parity-unpinned
+    model = model.to(dev).eval()
     B, S = args.batch, args.image_size
     g = torch.Generator().manual_seed(1234 + rank)
     low = (torch.rand(B, 3, S, S, generator=g) * 2 - 1).to(dev)      # synthetic low-light batch, resident in HBM
