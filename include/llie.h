@@ -106,7 +106,8 @@ int llie_param_info(const llie_ctx* ctx, int index, char* key_buf, size_t key_ca
  * `src` is a DEVICE pointer to the fp32 tensor in the reference's own layout (OIHW conv weights,
  * [out,in] Linear weights); the engine repacks it on `stream`. */
 int llie_load_param(llie_ctx* ctx, const char* key, const float* src, int64_t numel, llie_stream stream);
-/* Reload all parameters at once (after an optimiser step): srcs[i] = device fp32 tensor of parameter i in
+/* Reload all parameters at once -- what `optimizer.step()` implies for a module whose weights live outside PyTorch
+ * (src/training/trainer.py:300-318) and what `load_state_dict` does (scripts/inference.py:78-84): srcs[i] = device fp32 tensor of parameter i in
  * llie_param_info order (host array of n = llie_num_params pointers).  One kernel for all plain / 1x1 / 3x3 /
  * depthwise tensors; equivalent to n llie_load_param calls. */
 int llie_load_all(llie_ctx* ctx, const float* const* srcs, int n, llie_stream stream);
