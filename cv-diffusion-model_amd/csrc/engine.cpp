@@ -476,6 +476,10 @@ int build_module(llie_ctx* c) {
   switch (g.kind) {
     case LLIE_IRB:
       if (!gn_ok(g.in_channels) || !gn_ok(g.in_channels * g.expansion_ratio) || g.out_channels % 32) return LLIE_ERR_CONFIG;
+      // a two-tensor (virtual concat) input has no single tensor to add as the identity residual: like every
+      // concat-fed block of the network (efficient_unet.py:588), such a block needs Cin != Cout (skip conv)
+      if (g.base_channels > 0 && (g.in_channels == g.out_channels || g.base_channels % 32 || g.base_channels >= g.in_channels))
+        return LLIE_ERR_SHAPE;
       b.add_irb("", g.in_channels, g.out_channels, g.time_embed_dim, g.expansion_ratio, g.base_channels);
       // keys of a bare block have no leading dot
       break;

@@ -306,3 +306,13 @@ def test_unpinned_variants_are_opt_in_and_keep_reference_shapes(variant):
     assert list(got.items()) == list(want.items())
     m = M.LowLightDiffusion(unet_variant=variant, image_size=64, allow_unpinned_groupnorm=True)
     assert len(m.state_dict()) == len(want)
+
+
+def test_virtual_concat_block_needs_a_skip_conv():
+    """`concat_split` (the decoder's two-tensor input) with Cin == Cout would need an identity residual from two
+    tensors -- no block of the network has that shape; the engine rejects it instead of computing garbage (found by
+    tools/gpu_fuzz.py)."""
+    M.InvertedResidualBlock(96, 32, 128, concat_split=64)
+    for cin, split in [(64, 32), (128, 32), (96, 33), (96, 96)]:
+        with pytest.raises(ValueError):
+            M.InvertedResidualBlock(cin, cin if split < cin and split % 32 == 0 else 32, 128, concat_split=split)

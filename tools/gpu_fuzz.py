@@ -1,0 +1,89 @@
+#!/usr/bin/env python3
+"""Randomised differential test on the GPU box: single operators (forward and gradients) over random shapes
+(non-square maps, ragged batches, virtual-concat splits) against the CPU oracle + autograd.  Prints one line per case
+and a summary; exit code 1 if any case exceeds the tolerances used by tests/test_gpu_training.py.
+
+usage: gpu_fuzz.py [n_cases] [seed]
+"""
+import importlib, os, random, sys
+R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tests"))
+import torch
+from oracle import unet_ref
+from oracle.weightgen import synth_tensor
+from conftest import synth_input
+
+M = importlib.import_module("cv-diffusion-model_amd")
+dev = torch.device("cuda:0")
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+
+
+def rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
+
+
+def run(mod, name, fn, inputs):
+    mod.load_state_dict({k: synth_tensor(name + "." + k, tuple(v.shape)) for k, v in mod.state_dict().items()})
+    mod = mod.to(dev)
+    sd = {name + "." + k: v.detach().cpu().clone().requires_grad_(True) for k, v in mod.state_dict().items()}
+    xin = [x.clone().requires_grad_(True) for x in inputs]
+    y_ref = fn(sd, *xin)
+    w = synth_input(name + ".cot", tuple(y_ref.shape), -1, 1)
+    (y_ref * w).sum().backward()
+    din = [x.to(dev).requires_grad_(True) for x in inputs]
+    y = mod(*din)
+    (y * w.to(dev)).sum().backward()
+    errs = {"fwd": rel(y, y_ref)}
+    for i, (a, b) in enumerate(zip(din, xin)):
+        errs[f"dx{i}"] = rel(a.grad, b.grad)
+    for k, p in mod.named_parameters():
+        g = sd[name + "." + k].grad
+        if g is not None and g.abs().max() > 0:
+            errs[k] = rel(p.grad, g)
+    return errs
+
+
+bad = 0
+worst_all = 0.0
+for case in range(n_cases):
+    kind = rng.choice(["irb", "irb", "irb", "attn", "down", "up"])
+    b = rng.choice([1, 2, 3, 5])
+    if kind == "irb":
+        cin = rng.choice([32, 64, 96, 128, 192, 256]); cout = rng.choice([32, 64, 128, 256, cin])
+        h, w = rng.choice([8, 16, 24, 32, 40]), rng.choice([8, 16, 24, 32, 64])
+        split = rng.choice([0] + [s for s in (32, 64, 128) if s < cin]) if cin != cout else 0  # concat-fed blocks have a skip conv
+        while (h * w) % 64:
+            w += 8
+        name = f"fz{case}_irb"
+        mod = M.InvertedResidualBlock(cin, cout, 128, concat_split=split)
+        x = synth_input(name + ".x", (b, cin, h, w), -2, 2); te = synth_input(name + ".te", (b, 128), -1, 1)
+        desc = f"irb {cin}->{cout} split={split} {h}x{w} B={b}"
+        errs = run(mod, name, lambda sd, x, te: unet_ref.irb_forward(sd, name, x, te), [x, te])
+    elif kind == "attn":
+        c = rng.choice([64, 128, 256]); heads = rng.choice([2, 4, 8])
+        h, w = rng.choice([8, 16]), rng.choice([8, 16, 32])
+        name = f"fz{case}_attn"
+        mod = M.LinearAttention(c, heads)
+        x = synth_input(name + ".x", (b, c, h, w), -2, 2)
+        desc = f"attn C={c} heads={heads} {h}x{w} B={b}"
+        errs = run(mod, name, lambda sd, x: unet_ref.linear_attention_forward(sd, name, x, heads), [x])
+    else:
+        c = rng.choice([32, 64, 128]); h, w = rng.choice([16, 32, 48]), rng.choice([16, 32, 64])
+        name = f"fz{case}_{kind}"
+        if kind == "down":
+            mod = M.Downsample(c); x = synth_input(name + ".x", (b, c, h, w), -2, 2)
+            fn = lambda sd, x: unet_ref.downsample(sd, name, x)
+        else:
+            mod = M.Upsample(c); x = synth_input(name + ".x", (b, c, h // 2, w // 2), -2, 2)
+            fn = lambda sd, x: unet_ref.upsample(sd, name, x)
+        desc = f"{kind} C={c} {h}x{w} B={b}"
+        errs = run(mod, name, fn, [x])
+    worst = max(errs.values()); wk = max(errs, key=errs.get)
+    worst_all = max(worst_all, worst)
+    flag = "" if (errs["fwd"] < 1e-4 and worst < 1e-3) else "  <-- FAIL"
+    bad += bool(flag)
+    print(f"[{case:3d}] {desc:42s} fwd {errs['fwd']:.1e}  worst grad {worst:.1e} ({wk}){flag}", flush=True)
+print(f"{n_cases} cases, {bad} failures, worst error {worst_all:.2e}")
+sys.exit(1 if bad else 0)
