@@ -203,6 +203,9 @@ struct llie_ctx {
   struct GraphEntry { bool seen = false; hipGraphExec_t exec = nullptr; hipGraph_t graph = nullptr; };
   std::map<std::string, GraphEntry> graphs;
   hipStream_t cap_stream = nullptr;  // side stream used only to record captures (the legacy null stream cannot capture)
+  // backward pass: weight-gradient kernels run on this stream next to the activation-gradient chain (Back::fork/join)
+  hipStream_t side_stream = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   // per-kernel-class HIP-event profiling (llie_profile_begin / llie_profile_end)
   int prof_mask = 0;
   struct ProfRec { int cls; int64_t bytes; hipEvent_t e0, e1; const char* name; };
@@ -511,6 +514,9 @@ int build_module(llie_ctx* c) {
 // small@256 B=32 fp16; K1 without stores only drops 5.0 -> 4.6 ms), so it is opt-in: LLIE_DWX=1 or
 // llie_tune("dwx", 1).  See DESIGN.md section 7.
 bool g_use_dwx = getenv("LLIE_DWX") != nullptr;
+// Backward pass: run the weight-gradient kernels on a side stream next to the activation-gradient chain
+// (llie_tune("bwd_async", 0) puts everything back on the caller's stream).
+int g_bwd_async = 1;
 
 struct Run {
   llie_ctx* c;
@@ -912,6 +918,31 @@ struct Back {
   float* grads;
   hipError_t err = hipSuccess;
   std::map<size_t, size_t> gmap;  // forward tensor offset -> gradient offset
+  // Weight gradients do not feed the activation-gradient chain, so they run on a side stream (`async`): fork() makes
+  // the side stream wait for what the main stream has enqueued so far, defer() keeps a buffer the side stream may still
+  // read until join(), where the main stream waits for the side stream and the deferred buffers are released.  The dry
+  // run follows the same release order, so the workspace plan accounts for the longer lifetimes.
+  bool async = false;
+  hipStream_t s2 = nullptr;
+  std::vector<size_t> deferred;
+  hipStream_t side() const { return (async && s2) ? s2 : s; }
+  void fork() {
+    if (!async || dry || !s2) return;
+    chk(hipEventRecord(c->ev_fork, s));
+    chk(hipStreamWaitEvent(s2, c->ev_fork, 0));
+  }
+  void defer(size_t off) {
+    if (async) deferred.push_back(off);
+    else ar->free(off);
+  }
+  void join() {
+    if (async && !dry && s2) {
+      chk(hipEventRecord(c->ev_join, s2));
+      chk(hipStreamWaitEvent(s, c->ev_join, 0));
+    }
+    for (size_t off : deferred) ar->free(off);
+    deferred.clear();
+  }
 
   template <typename T = void> T* wptr(size_t off) const { return reinterpret_cast<T*>(c->blob + off); }
   template <typename T = void> T* p(size_t off) const { return reinterpret_cast<T*>(ws + off); }
@@ -965,9 +996,9 @@ struct Back {
       for (int i = 0; i < nseg; ++i) a.seg[i] = segs[i];
       a.B = B; a.Ho = geo.Ho; a.Wo = geo.Wo; a.Hi = geo.Hi; a.Wi = geo.Wi; a.stride = geo.stride; a.dy = geo.dy; a.dx = geo.dx;
       a.partial = p<float>(part); a.out = out; a.ldn = ldn; a.ldk = ldk; a.off = off; a.msplit = ms; a.ntap = ntap;
-      chk(launch_wgrad(dt, a, s));
+      chk(launch_wgrad(dt, a, side()));
     }
-    ar->free(part);
+    defer(part);
   }
 
   // activation backward + GroupNorm backward coefficients + norm parameter gradients at one norm site.
@@ -1034,7 +1065,8 @@ struct Back {
       dxs = alloc((size_t)M * cin * es());
       gemm(dY, cout, wptr<char>(w.w_proj_t) + (size_t)hid * cout * es(), dxs, cin, M, P);
     }
-    {  // project / skip weight gradients
+    {  // project / skip weight gradients (side stream: they only need dY, which the previous operator produced)
+      fork();
       GemmSeg sg[2];
       sg[0] = GemmSeg{dry ? nullptr : p(r.h2), hid, dry ? nullptr : p<float>(r.gate), nullptr, hid, ACT_NONE};
       wgrad(dY, cout, sg, 1, hid, g11, gp(pf + 10), hid, 1, 0);
@@ -1073,14 +1105,15 @@ struct Back {
         d.pool = nullptr; d.B = B; d.H = H; d.W = W; d.C = hid; d.no_act = 1;
         d.bx = p(r.h1.off); d.bas = p<float>(r.n2.as); d.bab = p<float>(r.n2.ab); d.bslab = p<float>(dzslab);
         chk(launch_dwconv3x3(dt, d, s));
+        fork();  // da3 and d(mean) are enqueued: the depthwise weight gradient may run beside the rest of the chain
         DwWgradArgs q{};
         q.g = p(da3); q.gs = p<float>(r.gate); q.gb = p<float>(dmean); q.h = p(r.h1.off); q.as = p<float>(r.n2.as);
         q.ab = p<float>(r.n2.ab); q.partial = p<float>(part); q.out = gp(pf + 5); q.B = B; q.H = H; q.W = W; q.C = hid;
-        chk(launch_dw_wgrad(dt, q, s));
+        chk(launch_dw_wgrad(dt, q, side()));
       }
-      ar->free(part);
+      defer(part);
     }
-    ar->free(da3); ar->free(dgate); ar->free(dpre2); ar->free(dr); ar->free(dmean);
+    defer(da3); ar->free(dgate); ar->free(dpre2); ar->free(dr); defer(dmean);
     // norm2 + FiLM + ReLU6
     const float* film = dry ? nullptr : p<float>(tp->film) + w.film_off;
     float* dfl = dry ? nullptr : p<float>(dfilm) + w.film_off;
@@ -1096,9 +1129,10 @@ struct Back {
       sg[0] = GemmSeg{dry ? nullptr : p(r.x0.off), r.x0.C, dry ? nullptr : p<float>(r.n1.as), dry ? nullptr : p<float>(r.n1.ab), cin, ACT_RELU6};
       if (x1) sg[1] = GemmSeg{dry ? nullptr : p(x1->off), x1->C, dry ? nullptr : p<float>(r.n1.as) + r.x0.C,
                               dry ? nullptr : p<float>(r.n1.ab) + r.x0.C, cin, ACT_RELU6};
+      fork();  // dh1 (in da2) is complete
       wgrad(da2, hid, sg, x1 ? 2 : 1, cin, g11, gp(pf + 4), cin, 1, 0);
     }
-    ar->free(da2);
+    defer(da2);
     // norm1 + ReLU6, then the block input (residual / skip-conv gradient added, existing gradients accumulated)
     Coef k1 = gn_site(da1, r.x0, x1, r.n1, ACT_RELU6, w.n1g, w.n1b, gp(pf + 0), gp(pf + 1), nullptr, 0, nullptr, 0);
     bool e0 = false, e1 = false;
@@ -1108,7 +1142,8 @@ struct Back {
     free_coef(k1);
     ar->free(da1);
     if (w.skip) ar->free(dxs);
-    ar->free(dY);
+    defer(dY);
+    join();
   }
 
   // ---- LinearAttention
@@ -1127,9 +1162,10 @@ struct Back {
     gemm(dtmp, C, wptr(w.w_out_t), dao, inner, M, N);
     {
       GemmSeg sg{dry ? nullptr : p(r.ao), inner, nullptr, nullptr, 0, ACT_NONE};
+      fork();
       wgrad(dtmp, C, &sg, 1, inner, g11, gp(pf + 3), inner, 1, 0);
     }
-    ar->free(dtmp);
+    defer(dtmp);
     // attention core
     const size_t dqkv = alloc((size_t)M * 3 * inner * es());
     {
@@ -1152,9 +1188,10 @@ struct Back {
     gemm(dqkv, 3 * inner, wptr(w.w_qkv_t), dxn, C, M, N);
     {
       GemmSeg sg{dry ? nullptr : p(r.x.off), C, dry ? nullptr : p<float>(r.n1.as), dry ? nullptr : p<float>(r.n1.ab), C, ACT_NONE};
+      fork();
       wgrad(dqkv, 3 * inner, &sg, 1, C, g11, gp(pf + 2), C, 1, 0);
     }
-    ar->free(dqkv);
+    defer(dqkv);
     // norm (no activation) + residual
     Coef k1 = gn_site(dxn, r.x, nullptr, r.n1, ACT_NONE, w.ng, w.nb, gp(pf + 0), gp(pf + 1), nullptr, 0, nullptr, 0);
     bool e0 = false;
@@ -1163,6 +1200,7 @@ struct Back {
     free_coef(k1);
     ar->free(dxn);
     ar->free(dY);
+    join();
   }
 
   // ---- Downsample / Upsample convolutions
@@ -1186,6 +1224,7 @@ struct Back {
     {
       GemmSeg sg{dry ? nullptr : p(src.off), C, nullptr, nullptr, 0, ACT_NONE};
       const Geo geo{Ho, Wo, src.H, src.W, r.up ? 1 : 2, 0, 0};
+      fork();
       wgrad(dY, C, &sg, 1, C, geo, gp(pf + 0), (int64_t)C * 9, 9, 0, 9);
     }
     // input gradient: stride-1 conv with flipped / transposed weights over dY (zero-dilated for the stride-2 conv)
@@ -1202,7 +1241,7 @@ struct Back {
       chk(launch_conv3x3(dt, a, s));
     }
     if (!r.up) ar->free(din);
-    ar->free(dY);
+    defer(dY);
     if (r.up) {
       const size_t dx = alloc((size_t)B * r.x.H * r.x.W * C * es());
       if (!dry) chk(launch_upsample2x_bwd(dt, p(dsrc), p(dx), B, r.x.H, r.x.W, C, s));
@@ -1211,6 +1250,7 @@ struct Back {
     } else {
       add_grad(r.x, dsrc);
     }
+    join();
   }
 
   void run_ops(size_t dfilm, int F) {
@@ -1409,6 +1449,9 @@ void llie_destroy(llie_ctx* c) {
     if (kv.second.graph) (void)hipGraphDestroy(kv.second.graph);
   }
   if (c->cap_stream) (void)hipStreamDestroy(c->cap_stream);
+  if (c->side_stream) (void)hipStreamDestroy(c->side_stream);
+  if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+  if (c->ev_join) (void)hipEventDestroy(c->ev_join);
   for (auto& r : c->prof) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
   for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
   if (c->blob) (void)hipFree(c->blob);
@@ -1603,6 +1646,19 @@ int llie_module_forward(llie_ctx* c, const float* x, const float* temb, float* y
 
 // ---------------------------------------------------------------------------------------------
 // Training: forward that keeps its activations + reverse pass over the tape.
+// side stream + events of the backward pass (created on first use); dry runs only copy the flag
+static int setup_async(llie_ctx* c, Back& b) {
+  b.async = g_bwd_async != 0;
+  if (!b.async || b.dry) return LLIE_OK;
+  hipError_t e = hipSuccess;
+  if (!c->side_stream) e = hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking);
+  if (e == hipSuccess && !c->ev_fork) e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
+  if (e == hipSuccess && !c->ev_join) e = hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming);
+  if (e != hipSuccess) { set_err("backward side stream: %s", hipGetErrorString(e)); return (int)e; }
+  b.s2 = c->side_stream;
+  return LLIE_OK;
+}
+
 int64_t llie_grad_numel(const llie_ctx* c) { return c ? c->grad_numel : LLIE_ERR_ARG; }
 int64_t llie_param_grad_offset(const llie_ctx* c, int i) {
   if (!c || i < 0 || i >= (int)c->params.size()) return LLIE_ERR_ARG;
@@ -1617,6 +1673,7 @@ int64_t llie_train_workspace_bytes(llie_ctx* c, int batch, int height, int width
   Run r{c, &ar, nullptr, nullptr, true, batch, c->dt};
   r.tape = &tape;
   Back b{c, &ar, nullptr, nullptr, true, batch, c->dt, &tape, nullptr};
+  setup_async(c, b);
   if (c->cfg.kind == LLIE_UNET) {
     r.unet(nullptr, nullptr, nullptr, 0, nullptr);
     b.unet(nullptr);
@@ -1659,6 +1716,7 @@ int llie_unet_backward(llie_ctx* c, const float* d_eps, float* grads, int batch,
     return LLIE_ERR_ARG;
   }
   Back b{c, c->train_arena, reinterpret_cast<hipStream_t>(stream), reinterpret_cast<char*>(ws), false, batch, c->dt, &c->tape, grads};
+  { const int rc = setup_async(c, b); if (rc) return rc; }
   b.unet(d_eps);
   if (c->train_arena->failed) { set_err("workspace too small for the backward pass"); return LLIE_ERR_WORKSPACE; }
   if (b.err != hipSuccess) { set_err("HIP error %d: %s", (int)b.err, hipGetErrorString(b.err)); return (int)b.err; }
@@ -1685,6 +1743,7 @@ int llie_module_backward(llie_ctx* c, const float* x, const float* temb, const f
   rc = finish_run(r, ws_bytes);
   if (rc) return rc;
   Back b{c, &ar, reinterpret_cast<hipStream_t>(stream), reinterpret_cast<char*>(ws), false, batch, c->dt, &tape, grads};
+  { const int rc2 = setup_async(c, b); if (rc2) return rc2; }
   b.module(r.mod_x1, temb, dy, dx, dtemb);
   if (ar.failed) { set_err("workspace too small for the backward pass"); return LLIE_ERR_WORKSPACE; }
   if (b.err != hipSuccess) { set_err("HIP error %d: %s", (int)b.err, hipGetErrorString(b.err)); return (int)b.err; }
@@ -1877,6 +1936,7 @@ int llie_tune(const char* knob, int value) {
   if (!strcmp(knob, "gemm_ablate")) { pw_gemm_debug(value); return LLIE_OK; }
   if (!strcmp(knob, "dw_ablate")) { dwconv_debug(value); return LLIE_OK; }
   if (!strcmp(knob, "dw_swap")) { dwconv_swap(value); return LLIE_OK; }
+  if (!strcmp(knob, "bwd_async")) { g_bwd_async = value; return LLIE_OK; }
   if (!strcmp(knob, "wgrad_target")) { wgrad_set_target(value); return LLIE_OK; }
   return LLIE_ERR_ARG;
 }
