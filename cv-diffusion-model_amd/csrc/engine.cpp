@@ -1288,9 +1288,10 @@ struct Back {
         a.da = p(da); a.partial = p<float>(part); a.dw = gp(pidx("final_conv.weight")); a.dbias = gp(pidx("final_conv.bias"));
         a.B = B; a.H = S; a.W = S; a.C = C0; a.Cout = g.out_channels;
         chk(launch_final_bwd_data(dt, a, s));
-        chk(launch_final_bwd_weight(dt, a, s));
+        fork();  // the head's weight gradient only needs d(eps) and forward tensors
+        chk(launch_final_bwd_weight(dt, a, side()));
       }
-      ar->free(part);
+      defer(part);  // released at the first operator's join
     }
     Coef kf = gn_site(da, tp->hlast, nullptr, tp->fin, ACT_SILU, c->fin_g, c->fin_b, gp(pidx("final_norm.weight")),
                       gp(pidx("final_norm.bias")), nullptr, 0, nullptr, 0);
