@@ -321,6 +321,9 @@ def test_full_size_properties_small256_b32_fp16(dev):
         assert torch.equal(a.enhanced, a.intermediate[-1].clamp(-1, 1))
         sub = m.enhance(low[8:13], 4, noise=noise[:, 8:13], return_intermediate=True)  # ragged sub-batch of 5
         assert torch.equal(sub.intermediate[-1], a.intermediate[-1][8:13])  # rows do not depend on batch mates
+        # a 2-image batch against the 32-image one
+        sub2 = m.enhance(low[3:5], 4, noise=noise[:, 3:5], return_intermediate=True)
+        assert torch.equal(sub2.intermediate[-1], a.intermediate[-1][3:5])
         perm = torch.randperm(32)
         c = m.enhance(low[perm], 4, noise=noise[:, perm], return_intermediate=True)
         assert torch.equal(c.intermediate[-1], a.intermediate[-1][perm])    # permutation equivariance
