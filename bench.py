@@ -157,11 +157,19 @@ def main() -> None:
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    # Rehearsal on a one-GPU box (the multi-rank code path otherwise only ever runs on the driver's 8-GPU node):
+    # LLIE_BENCH_REHEARSAL=1 puts every rank on cuda:0 and uses gloo (RCCL wants one device per rank).
+    rehearsal = os.environ.get("LLIE_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     M = importlib.import_module("cv-diffusion-model_amd")
     torch.manual_seed(0)
@@ -177,13 +185,28 @@ def main() -> None:
     B, S = args.batch, args.image_size
     g = torch.Generator().manual_seed(1234 + rank)
     low = (torch.rand(B, 3, S, S, generator=g) * 2 - 1).to(dev)      # synthetic low-light batch, resident in HBM
-    gather_buf = torch.empty(world * B, 3, S, S, device=dev) if world > 1 else None
+    # The path's only collective: all_gather of the outputs.  It is issued asynchronously (RCCL runs it on its own
+    # stream) into one of two buffers, so step k's gather overlaps step k+1's compute; a buffer is reused only after
+    # its previous gather has been waited for, and the last gather is waited for before the closing barrier.
+    gather_bufs = [torch.empty(world * B, 3, S, S, device=dev) for _ in range(2)] if world > 1 else None
+    pending = [None, None]
+    nstep = [0]
 
     def step():
         out = model.enhance(low, args.lcm_steps)                     # noise drawn on device, reference order
         if world > 1:
-            dist.all_gather_into_tensor(gather_buf, out)              # the path's only collective
+            i = nstep[0] & 1
+            if pending[i] is not None:
+                pending[i].wait()
+            pending[i] = dist.all_gather_into_tensor(gather_bufs[i], out, async_op=True)
+            nstep[0] += 1
         return out
+
+    def drain():
+        for i in (0, 1):
+            if pending[i] is not None:
+                pending[i].wait()
+                pending[i] = None
 
     log(f"model built on {dev}; warm-up x{args.warmup}")
     native = importlib.import_module("cv-diffusion-model_amd._native")
@@ -194,6 +217,7 @@ def main() -> None:
         if prof and i == args.warmup - 1:       # last warm-up step: per-kernel breakdown of every profiled class
             handle.profile_begin(native.K_DW | native.K_GEMM | native.K_CONV3 | native.K_SE)
         step()
+    drain()
     torch.cuda.synchronize()
     dom_class = native.K_DW
     if prof and args.warmup > 0:
@@ -209,6 +233,7 @@ def main() -> None:
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    drain()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
