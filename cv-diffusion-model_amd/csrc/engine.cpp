@@ -512,7 +512,7 @@ int build_module(llie_ctx* c) {
 // Fused expand+depthwise ("recompute" form, dwx.hip) for 2-byte dtypes.  Numerically equivalent, but as
 // built it is slower than the unfused pair on MI355X (6.2 vs 3.6 ms/forward for the depthwise class at
 // small@256 B=32 fp16; K1 without stores only drops 5.0 -> 4.6 ms), so it is opt-in: LLIE_DWX=1 or
-// llie_tune("dwx", 1).  See DESIGN.md section 7.
+// llie_tune("dwx", 1).  See DESIGN.md section 8.
 bool g_use_dwx = getenv("LLIE_DWX") != nullptr;
 // Backward pass: run the weight-gradient kernels on a side stream next to the activation-gradient chain
 // (llie_tune("bwd_async", 0) puts everything back on the caller's stream).

@@ -312,7 +312,7 @@ static hipError_t launch_t(const GemmArgs& a, hipStream_t s) {
 }
 
 // g_gemm_v2: the LDS-DMA pipelined variant (gemm2.hip) is numerically equivalent but measured 1.4x slower on
-// MI355X over the layer shapes of small@256 (DESIGN.md section 7), so it is opt-in: llie_tune("gemm_v2", 1).
+// MI355X over the layer shapes of small@256 (DESIGN.md section 8), so it is opt-in: llie_tune("gemm_v2", 1).
 static int g_gemm_dbg = 0, g_gemm_v2 = 0;
 void pw_gemm_debug(int v) { g_gemm_dbg = v; }
 void pw_gemm_use_v2(int v) { g_gemm_v2 = v; }
