@@ -137,6 +137,16 @@ __device__ __forceinline__ void dw_body(const DwArgs& a, const int TYL, const in
       if (r >= nrows) break;  // uniform over the workgroup
       const int gy = y0 - 1 + r;
       const bool row_ok = gy >= 0 && gy < a.H;
+      if constexpr (BWD && std::is_same<T, bf16_t>::value) {
+        // bf16 has no mixed-precision FMA: left alone, the compiler hoists the 72 weight conversions out of the row
+        // loop and the backward instantiation lands at 256 VGPRs (one wave per SIMD).  Making the packed weights
+        // opaque once per row keeps them packed (36 VGPRs) and re-converts at use: more VALU, twice the occupancy.
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+          u32x4& wq = reinterpret_cast<u32x4&>(w[t]);
+          asm volatile("" : "+v"(wq));
+        }
+      }
       vec_t* buf = ring[j & 1];  // r0 is a multiple of 12, so r & 1 == j & 1, r % 4 == j % 4, r % 3 == j % 3
       buf[(xl + 1) * 8 + cl] = row_ok ? ((dbg & 2) ? pre[j % 4] : activate(pre[j % 4])) : zero;
       if (is_halo) buf[hslot * 8 + cl] = (row_ok && hx_ok) ? activate(preh[j % 4]) : zero;
