@@ -301,7 +301,7 @@ static int dwg_tx(int W) { return (W % 32 == 0) ? 32 : ((W % 16 == 0) ? 16 : 8);
 int dw_wgrad_strips(int H, int W) { return (W / dwg_tx(W)) * ((H + kDwgTY - 1) / kDwgTY); }
 
 template <typename T, int TX>
-__global__ void __launch_bounds__(8 * TX) dw_wgrad_kernel(const DwWgradArgs a) {
+__global__ void __launch_bounds__(8 * TX, 3) dw_wgrad_kernel(const DwWgradArgs a) {  // 3 waves per SIMD: 170 VGPRs (the unconstrained allocation lands 4 above)
   constexpr int VEC = Elem<T>::VEC, CC = 8 * VEC, PW = TX + 2;
   typedef typename Elem<T>::vec_t vec_t;
   __shared__ vec_t ring[2][PW * 8];
