@@ -137,10 +137,10 @@ __device__ __forceinline__ void dw_body(const DwArgs& a, const int TYL, const in
       if (r >= nrows) break;  // uniform over the workgroup
       const int gy = y0 - 1 + r;
       const bool row_ok = gy >= 0 && gy < a.H;
-      if constexpr (BWD && std::is_same<T, bf16_t>::value) {
+      if constexpr (std::is_same<T, bf16_t>::value) {
         // bf16 has no mixed-precision FMA: left alone, the compiler hoists the 72 weight conversions out of the row
-        // loop and the backward instantiation lands at 256 VGPRs (one wave per SIMD).  Making the packed weights
-        // opaque once per row keeps them packed (36 VGPRs) and re-converts at use: more VALU, twice the occupancy.
+        // loop (forward 216 VGPRs, backward 256 = one wave per SIMD).  Making the packed weights opaque once per row
+        // keeps them packed (36 VGPRs) and re-converts at use: more VALU, one more wave per SIMD.
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
           u32x4& wq = reinterpret_cast<u32x4&>(w[t]);
@@ -233,7 +233,8 @@ __device__ __forceinline__ void dw_body(const DwArgs& a, const int TYL, const in
 }
 
 template <typename T, int TX, int PFV>
-__global__ void __launch_bounds__(8 * TX) dwconv3x3_kernel(const DwArgs a, const int TYL, const int dbg, const int swap) {
+__global__ void __launch_bounds__(8 * TX, (std::is_same<T, bf16_t>::value ? 3 : 1))
+dwconv3x3_kernel(const DwArgs a, const int TYL, const int dbg, const int swap) {
   dw_body<T, TX, PFV, false>(a, TYL, dbg, swap);
 }
 template <typename T, int TX, int PFV>
