@@ -739,185 +739,38 @@ hipError_t launch_final_bwd_data(int dtype, const FinalBwdArgs& a, hipStream_t s
   }
   return hipGetLastError();
 }
-// weight gradient: dW[o][c][tap] = sum_{b,p} deps[o][p] * a[p + tap - 1][c].  Block = 8 image rows; thread =
-// (channel c, pixel lane); partial[blk][o*9 + tap][c], partial bias sums in row Cout*9 (channel index = o).
-constexpr int kHeadRows = 2;
+// The weight gradients of the output head and of the input conv run on the MFMA weight-gradient GEMM (wgrad.hip, nine
+// taps per launch) once their fp32 NCHW planes are packed into a 32-channel NHWC T tensor (channels beyond the real
+// ones are zero): [B][c0 (+c1)][P] -> [B*P][32].
 template <typename T>
-__global__ void __launch_bounds__(256) final_bwd_weight_kernel(const FinalBwdArgs a) {
-  extern __shared__ float red[];  // [lanes][C]
-  const int tid = threadIdx.x, c = tid % a.C, pl = tid / a.C, lanes = 256 / a.C;
-  const int b = blockIdx.y, y0 = blockIdx.x * kHeadRows;
-  const size_t plane = (size_t)a.H * a.W;
-  const float sc = a.as[(size_t)b * a.C + c], sh = a.ab[(size_t)b * a.C + c];
-  const T* hp = reinterpret_cast<const T*>(a.h) + (size_t)b * plane * a.C + c;
-  float acc[4 * 9], bsum[4];
+__global__ void __launch_bounds__(256) pack_planes_kernel(const float* x0, const float* x1, int c0, int c1, T* out, int B, int P) {
+  constexpr int VEC = Elem<T>::VEC;
+  const size_t m = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (m >= (size_t)B * P) return;
+  const int b = (int)(m / P);
+  const size_t p = m % P;
+  float v[32];
 #pragma unroll
-  for (int i = 0; i < 36; ++i) acc[i] = 0.f;
+  for (int c = 0; c < 32; ++c) v[c] = 0.f;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) bsum[i] = 0.f;
-  for (int i = pl; i < kHeadRows * a.W; i += lanes) {
-    const int y = y0 + i / a.W, x = i % a.W;
-    float d[4];
-#pragma unroll
-    for (int o = 0; o < 4; ++o) d[o] = o < a.Cout ? a.deps[((size_t)b * a.Cout + o) * plane + (size_t)y * a.W + x] : 0.f;
-#pragma unroll
-    for (int o = 0; o < 4; ++o) bsum[o] += d[o];
-#pragma unroll
-    for (int ky = 0; ky < 3; ++ky) {
-      const int yy = y + ky - 1;
-      if (yy < 0 || yy >= a.H) continue;
-#pragma unroll
-      for (int kx = 0; kx < 3; ++kx) {
-        const int xx = x + kx - 1;
-        if (xx < 0 || xx >= a.W) continue;
-        const float av = round_to<T>(siluf((float)hp[((size_t)yy * a.W + xx) * a.C] * sc + sh));
-#pragma unroll
-        for (int o = 0; o < 4; ++o) acc[o * 9 + ky * 3 + kx] += d[o] * av;
-      }
-    }
+  for (int c = 0; c < 8; ++c) {
+    if (c < c0) v[c] = x0[((size_t)b * c0 + c) * P + p];
+    else if (c < c0 + c1) v[c] = x1[((size_t)b * c1 + (c - c0)) * P + p];
   }
-  // all sums of the block through LDS at once: red[lane][row][c]; the bias row holds bsum[o] at channel index o
-  const int rows = a.Cout * 9 + 1;
-  float* out = a.partial + ((size_t)b * gridDim.x + blockIdx.x) * rows * a.C;
 #pragma unroll
-  for (int j = 0; j < 36; ++j) {
-    if (j >= a.Cout * 9) break;
-    red[((size_t)pl * rows + j) * a.C + c] = acc[j];
-  }
-  if (c == 0) {  // every thread of a lane saw the same pixels: channel 0's thread stores the lane's bias sums
-#pragma unroll
-    for (int o = 0; o < 4; ++o)
-      if (o < a.Cout) red[((size_t)pl * rows + a.Cout * 9) * a.C + o] = bsum[o];
-  }
-  __syncthreads();
-  for (int i = tid; i < rows * a.C; i += 256) {
-    if (i >= a.Cout * 9 * a.C && i - a.Cout * 9 * a.C >= a.Cout) continue;  // unused tail of the bias row
-    float v = 0.f;
-    for (int q = 0; q < lanes; ++q) v += red[(size_t)q * rows * a.C + i];
-    out[i] = v;
-  }
+  for (int q = 0; q < 32 / VEC; ++q) st_f32<T>(out + m * 32 + q * VEC, v + q * VEC);
 }
-__global__ void final_bwd_weight_reduce_kernel(const float* partial, float* dw, float* dbias, int nparts, int C, int Cout) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  const int rows = Cout * 9 + 1;
-  if (i < Cout * 9 * C) {
-    const int j = i / C, c = i % C;  // j = o*9 + tap
-    float s = 0.f;
-    for (int p = 0; p < nparts; ++p) s += partial[((size_t)p * rows + j) * C + c];
-    const int o = j / 9, tap = j % 9;
-    dw[((size_t)o * C + c) * 9 + tap] = s;
-  } else if (i < Cout * 9 * C + Cout) {
-    const int o = i - Cout * 9 * C;
-    float s = 0.f;
-    for (int p = 0; p < nparts; ++p) s += partial[((size_t)p * rows + Cout * 9) * C + o];
-    dbias[o] = s;
-  }
-}
-hipError_t launch_final_bwd_weight(int dtype, const FinalBwdArgs& a, hipStream_t s) {
-  if (a.C > 256 || 256 % a.C || a.Cout > 4 || a.H % kHeadRows) return hipErrorInvalidValue;
-  dim3 grid(a.H / kHeadRows, a.B);
-  const size_t lds = (size_t)256 * (a.Cout * 9 + 1) * sizeof(float);  // [256 / C lanes][rows][C]
+hipError_t launch_pack_planes(int dtype, const float* x0, const float* x1, int c0, int c1, void* out, int B, int P, hipStream_t s) {
+  if (c0 + c1 > 8 || c0 < 1) return hipErrorInvalidValue;
+  dim3 grid((unsigned)(((size_t)B * P + 255) / 256));
   switch (dtype) {
-    case 0: hipLaunchKernelGGL(final_bwd_weight_kernel<float>, grid, dim3(256), lds, s, a); break;
-    case 1: hipLaunchKernelGGL(final_bwd_weight_kernel<half_t>, grid, dim3(256), lds, s, a); break;
-    case 2: hipLaunchKernelGGL(final_bwd_weight_kernel<bf16_t>, grid, dim3(256), lds, s, a); break;
+    case 0: hipLaunchKernelGGL(pack_planes_kernel<float>, grid, dim3(256), 0, s, x0, x1, c0, c1, (float*)out, B, P); break;
+    case 1: hipLaunchKernelGGL(pack_planes_kernel<half_t>, grid, dim3(256), 0, s, x0, x1, c0, c1, (half_t*)out, B, P); break;
+    case 2: hipLaunchKernelGGL(pack_planes_kernel<bf16_t>, grid, dim3(256), 0, s, x0, x1, c0, c1, (bf16_t*)out, B, P); break;
     default: return hipErrorInvalidValue;
   }
-  const int n = a.Cout * 9 * a.C + a.Cout;
-  int nparts = a.B * (a.H / kHeadRows);
-  const int64_t nk = (int64_t)(a.Cout * 9 + 1) * a.C;
-  if (nparts > kPartGroups) {
-    hipLaunchKernelGGL(partial_groups_kernel, dim3((unsigned)((nk + 255) / 256), kPartGroups), dim3(256), 0, s, a.partial, nk, nparts);
-    nparts = kPartGroups;
-  }
-  hipLaunchKernelGGL(final_bwd_weight_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, s, a.partial, a.dw, a.dbias,
-                     nparts, a.C, a.Cout);
   return hipGetLastError();
 }
-
-constexpr int kInitPass = 16;  // rows per LDS pass of the block reduction (16 KB)
-// ---- input conv weight gradient: dW[co][ci][tap] = sum_{b,p} g[p][co] * x[ci][p + tap - 1]  (x fp32 NCHW planes)
-template <typename T>
-__global__ void __launch_bounds__(256) init_bwd_weight_kernel(const InitBwdArgs a) {
-  extern __shared__ float red[];
-  const int tid = threadIdx.x, co = tid % a.Cout, pl = tid / a.Cout, lanes = 256 / a.Cout;
-  const int b = blockIdx.y, y0 = blockIdx.x * kHeadRows, Cin = a.c0 + a.c1;
-  const size_t plane = (size_t)a.H * a.W;
-  const T* gp = reinterpret_cast<const T*>(a.g) + (size_t)b * plane * a.Cout + co;
-  float acc[8 * 9], bsum = 0.f;
-#pragma unroll
-  for (int i = 0; i < 72; ++i) acc[i] = 0.f;
-  for (int i = pl; i < kHeadRows * a.W; i += lanes) {
-    const int y = y0 + i / a.W, x = i % a.W;
-    const float g = (float)gp[((size_t)y * a.W + x) * a.Cout];
-    bsum += g;
-#pragma unroll
-    for (int ci = 0; ci < 8; ++ci) {
-      if (ci >= Cin) break;
-      const float* xp = ci < a.c0 ? a.x0 + ((size_t)b * a.c0 + ci) * plane : a.x1 + ((size_t)b * a.c1 + (ci - a.c0)) * plane;
-#pragma unroll
-      for (int ky = 0; ky < 3; ++ky) {
-        const int yy = y + ky - 1;
-        if (yy < 0 || yy >= a.H) continue;
-#pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
-          const int xx = x + kx - 1;
-          if (xx < 0 || xx >= a.W) continue;
-          acc[ci * 9 + ky * 3 + kx] += g * round_to<T>(xp[(size_t)yy * a.W + xx]);
-        }
-      }
-    }
-  }
-  // the (row, channel) sums of the block go through LDS in passes of kInitPass rows: red[lane][row][co]
-  const int rows = Cin * 9 + 1;
-  float* out = a.partial + ((size_t)b * gridDim.x + blockIdx.x) * rows * a.Cout;
-  for (int j0 = 0; j0 < rows; j0 += kInitPass) {
-    const int nr = min(kInitPass, rows - j0);
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < 73; ++j) {
-      if (j >= j0 && j < j0 + nr) red[((size_t)pl * kInitPass + (j - j0)) * a.Cout + co] = j < Cin * 9 ? acc[j < 72 ? j : 0] : bsum;
-    }
-    __syncthreads();
-    for (int i = tid; i < nr * a.Cout; i += 256) {
-      float v = 0.f;
-      for (int q = 0; q < lanes; ++q) v += red[(size_t)q * kInitPass * a.Cout + i];
-      out[(size_t)j0 * a.Cout + i] = v;
-    }
-  }
-}
-__global__ void init_bwd_weight_reduce_kernel(const float* partial, float* dw, float* dbias, int nparts, int Cin, int Cout) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  const int rows = Cin * 9 + 1;
-  if (i >= rows * Cout) return;
-  const int j = i / Cout, co = i % Cout;
-  float s = 0.f;
-  for (int p = 0; p < nparts; ++p) s += partial[((size_t)p * rows + j) * Cout + co];
-  if (j < Cin * 9) dw[((size_t)co * Cin + j / 9) * 9 + j % 9] = s;
-  else dbias[co] = s;
-}
-hipError_t launch_init_bwd_weight(int dtype, const InitBwdArgs& a, hipStream_t s) {
-  const int Cin = a.c0 + a.c1;
-  if (a.Cout > 256 || 256 % a.Cout || Cin > 8 || a.H % kHeadRows) return hipErrorInvalidValue;
-  dim3 grid(a.H / kHeadRows, a.B);
-  const size_t lds = (size_t)256 * kInitPass * sizeof(float);  // [256 / Cout lanes][kInitPass rows][Cout]
-  switch (dtype) {
-    case 0: hipLaunchKernelGGL(init_bwd_weight_kernel<float>, grid, dim3(256), lds, s, a); break;
-    case 1: hipLaunchKernelGGL(init_bwd_weight_kernel<half_t>, grid, dim3(256), lds, s, a); break;
-    case 2: hipLaunchKernelGGL(init_bwd_weight_kernel<bf16_t>, grid, dim3(256), lds, s, a); break;
-    default: return hipErrorInvalidValue;
-  }
-  const int n = (Cin * 9 + 1) * a.Cout;
-  int nparts = a.B * (a.H / kHeadRows);
-  if (nparts > kPartGroups) {
-    hipLaunchKernelGGL(partial_groups_kernel, dim3((n + 255) / 256, kPartGroups), dim3(256), 0, s, a.partial, (int64_t)n, nparts);
-    nparts = kPartGroups;
-  }
-  hipLaunchKernelGGL(init_bwd_weight_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, s, a.partial, a.dw, a.dbias,
-                     nparts, Cin, a.Cout);
-  return hipGetLastError();
-}
-
 // =============================================================================================
 // (8) linear attention backward (forward: efficient_unet.py:288-302).  With Q = phi(q), K = phi(k):
 //   den = Q.ks + 1e-6, out = (Q kv)/den;  dnum = dout/den, dden = -sum_e dout*out/den

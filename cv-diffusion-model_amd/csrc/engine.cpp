@@ -991,7 +991,7 @@ struct Back {
   }
   struct Geo { int Ho, Wo, Hi, Wi, stride, dy, dx; };
   void wgrad(size_t g, int N, const GemmSeg* segs, int nseg, int K, Geo geo, float* out, int64_t ldn, int64_t ldk, int64_t off,
-             int ntap = 1) {
+             int ntap = 1, int nstore = 0, int kstore = 0) {
     const int M = B * geo.Ho * geo.Wo;
     const int ms = wgrad_msplit(dt, M, N, K, ntap);
     const size_t part = alloc((size_t)ms * ntap * N * K * 4);
@@ -1000,7 +1000,7 @@ struct Back {
       a.g = p(g); a.N = N; a.nseg = nseg; a.K = K;
       for (int i = 0; i < nseg; ++i) a.seg[i] = segs[i];
       a.B = B; a.Ho = geo.Ho; a.Wo = geo.Wo; a.Hi = geo.Hi; a.Wi = geo.Wi; a.stride = geo.stride; a.dy = geo.dy; a.dx = geo.dx;
-      a.partial = p<float>(part); a.out = out; a.ldn = ldn; a.ldk = ldk; a.off = off; a.msplit = ms; a.ntap = ntap;
+      a.partial = p<float>(part); a.out = out; a.ldn = ldn; a.ldk = ldk; a.off = off; a.msplit = ms; a.ntap = ntap; a.nstore = nstore; a.kstore = kstore;
       chk(launch_wgrad(dt, a, side()));
     }
     defer(part);
@@ -1286,17 +1286,30 @@ struct Back {
     // output head
     const size_t da = alloc((size_t)M * C0 * es());
     {
-      const size_t part = alloc((size_t)B * (S / 2) * (g.out_channels * 9 + 1) * C0 * 4);
+      // weight gradient of the head on the MFMA weight-gradient GEMM: d(eps) packed to [M][32] NHWC is the "g"
+      // operand (3 real rows), silu(norm(h)) recomputed in the prologue the other; bias = plane sums of d(eps).
+      // It only needs d(eps) and forward tensors: side stream, joined with the first operator.
+      const size_t g32 = alloc((size_t)M * 32 * es());
+      const int nt = P / 64;
+      const size_t bslab = alloc((size_t)B * nt * 2 * 32 * 4), bS = alloc((size_t)B * 32 * 4);
       if (!dry) {
         FinalBwdArgs a{};
-        a.deps = deps; a.w = wptr<float>(c->fin_w); a.h = p(tp->hlast.off); a.as = p<float>(tp->fin.as); a.ab = p<float>(tp->fin.ab);
-        a.da = p(da); a.partial = p<float>(part); a.dw = gp(pidx("final_conv.weight")); a.dbias = gp(pidx("final_conv.bias"));
+        a.deps = deps; a.w = wptr<float>(c->fin_w); a.da = p(da);
         a.B = B; a.H = S; a.W = S; a.C = C0; a.Cout = g.out_channels;
         chk(launch_final_bwd_data(dt, a, s));
-        fork();  // the head's weight gradient only needs d(eps) and forward tensors
-        chk(launch_final_bwd_weight(dt, a, side()));
+        fork();
+        chk(launch_pack_planes(dt, deps, nullptr, g.out_channels, 0, p(g32), B, P, side()));
+        BwdMaskArgs m{};  // bias gradient = column sums of the packed d(eps)
+        m.g = p(g32); m.act = ACT_NONE; m.slab = p<float>(bslab); m.M = M; m.C = 32; m.P = P;
+        chk(launch_bwd_mask_reduce(dt, m, side()));
+        chk(launch_slab_reduce(p<float>(bslab), p<float>(bS), B, nt, 2, 1, 32, side()));
+        chk(launch_batch_sum(p<float>(bS), gp(pidx("final_conv.bias")), B, 32, g.out_channels, side()));
       }
-      defer(part);  // released at the first operator's join
+      defer(bslab); defer(bS);
+      GemmSeg sg{dry ? nullptr : p(tp->hlast.off), C0, dry ? nullptr : p<float>(tp->fin.as), dry ? nullptr : p<float>(tp->fin.ab), C0, ACT_SILU};
+      const Geo geo{S, S, S, S, 1, 0, 0};
+      wgrad(g32, 32, &sg, 1, C0, geo, gp(pidx("final_conv.weight")), (int64_t)C0 * 9, 9, 0, 9, g.out_channels, 0);
+      defer(g32);  // released at the first operator's join
     }
     Coef kf = gn_site(da, tp->hlast, nullptr, tp->fin, ACT_SILU, c->fin_g, c->fin_b, gp(pidx("final_norm.weight")),
                       gp(pidx("final_norm.bias")), nullptr, 0, nullptr, 0);
@@ -1306,16 +1319,27 @@ struct Back {
     run_ops(dfilm, F);
     // input conv
     {
+      // dW[co][ci][tap] on the same GEMM: g = d(h0) [M][C0], the other operand the two fp32 input planes packed to
+      // [M][32] NHWC (6 real channels); bias = column sums of d(h0)
       const size_t g0 = take_grad(tp->h0);
-      const int half = g.in_channels / 2;
-      const size_t part = alloc((size_t)B * (S / 2) * (g.in_channels * 9 + 1) * C0 * 4);
+      const int half = g.in_channels / 2, nt = P / 64;
+      const size_t x32 = alloc((size_t)M * 32 * es());
+      const size_t slab = alloc((size_t)B * nt * 2 * C0 * 4), S1 = alloc((size_t)B * C0 * 4);
       if (!dry) {
-        InitBwdArgs a{};
-        a.g = p(g0); a.x0 = tp->lat; a.x1 = tp->cond; a.c0 = half; a.c1 = g.in_channels - half; a.partial = p<float>(part);
-        a.dw = gp(pidx("init_conv.weight")); a.dbias = gp(pidx("init_conv.bias")); a.B = B; a.H = S; a.W = S; a.Cout = C0;
-        chk(launch_init_bwd_weight(dt, a, s));
+        chk(launch_pack_planes(dt, tp->lat, tp->cond, half, g.in_channels - half, p(x32), B, P, s));
+        BwdMaskArgs m{};
+        m.g = p(g0); m.act = ACT_NONE; m.slab = p<float>(slab); m.M = M; m.C = C0; m.P = P;
+        chk(launch_bwd_mask_reduce(dt, m, s));
+        chk(launch_slab_reduce(p<float>(slab), p<float>(S1), B, nt, 2, 1, C0, s));
+        chk(launch_batch_sum(p<float>(S1), gp(pidx("init_conv.bias")), B, C0, c->channels_r[0], s));
       }
-      ar->free(part); ar->free(g0);
+      GemmSeg sg{dry ? nullptr : p(x32), 32, nullptr, nullptr, 0, ACT_NONE};
+      const Geo geo{S, S, S, S, 1, 0, 0};
+      fork();
+      wgrad(g0, C0, &sg, 1, 32, geo, gp(pidx("init_conv.weight")), (int64_t)g.in_channels * 9, 9, 0, 9, c->channels_r[0], g.in_channels);
+      ar->free(slab); ar->free(S1);
+      defer(x32); defer(g0);
+      join();
     }
     // time embedding MLP (efficient_unet.py:412-417): temb = W3 silu(W1 emb + b1) + b3, FiLM reads silu(temb)
     const int dim = g.base_channels;

@@ -314,6 +314,7 @@ struct WgradArgs {
   GemmSeg seg[3]; int nseg; int K;
   int B, Ho, Wo, Hi, Wi, stride, dy, dx;
   int ntap;            // 1, or 9: all taps of a 3x3 weight in one launch (dy, dx ignored; tap t lands at off + t)
+  int nstore, kstore;  // only rows n < nstore / columns k < kstore are stored (0 = all): operands padded to 32 channels
   float* partial;      // [msplit][ntap][N][K] scratch
   float* out; int64_t ldn, ldk, off;
   int msplit;
@@ -361,20 +362,13 @@ hipError_t launch_cvt_rows_t(int dtype, const float* src, void* dst, int rows, i
 //   output head: d(eps) fp32 NCHW [B][Cout][H][W] -> da NHWC [M][C] T (gradient of the SiLU output), and its weight gradient
 struct FinalBwdArgs {
   const float* deps; const float* w;       // w: the forward kernel's repacked fp32 weights [9][C][4]
-  const void* h; const float* as; const float* ab;   // forward input of the final norm and its affine (SiLU follows)
   void* da;                                 // [M][C] T
-  float* partial; float* dw; float* dbias;  // partial: [B*H/8][Cout*9][C]; dw OIHW; dbias [Cout]
   int B, H, W, C, Cout;
 };
 hipError_t launch_final_bwd_data(int dtype, const FinalBwdArgs& a, hipStream_t s);
-hipError_t launch_final_bwd_weight(int dtype, const FinalBwdArgs& a, hipStream_t s);
-//   input conv: weight gradient from d(h0) NHWC [M][Cout] T and the fp32 NCHW input planes
-struct InitBwdArgs {
-  const void* g; const float* x0; const float* x1; int c0, c1;
-  float* partial; float* dw; float* dbias;  // partial [B*H/8][Cin*9 + 1][Cout]; dw OIHW [Cout][Cin][3][3]
-  int B, H, W, Cout;
-};
-hipError_t launch_init_bwd_weight(int dtype, const InitBwdArgs& a, hipStream_t s);
+//   fp32 NCHW planes ([B][c0][P] and optionally [B][c1][P]) -> NHWC T [B*P][32], zero beyond the real channels: the
+//   operand layout launch_wgrad wants (weight gradients of the output head and of the input conv)
+hipError_t launch_pack_planes(int dtype, const float* x0, const float* x1, int c0, int c1, void* out, int B, int P, hipStream_t s);
 
 // (8) linear attention backward.  qkv / dqkv NHWC [B][N][3*inner]; kv = forward partials [nsplit][B][heads][32][33].
 struct AttnBwdArgs {

@@ -193,7 +193,7 @@ __global__ void __launch_bounds__(256) wgrad_reduce1_kernel(float* partial, int6
   partial[(size_t)g * nk + i] = s;
 }
 __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* partial, float* out, int N, int K, int ntap, int msplit,
-                                                           int64_t ldn, int64_t ldk, int64_t off) {
+                                                           int64_t ldn, int64_t ldk, int64_t off, int nstore, int kstore) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int64_t tot = (int64_t)ntap * N * K;
   if (i >= tot) return;
@@ -202,7 +202,7 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* partial,
   const int tap = (int)(i / ((int64_t)N * K));
   const int64_t j = i % ((int64_t)N * K);
   const int n = (int)(j / K), k = (int)(j % K);
-  out[(size_t)n * ldn + (size_t)k * ldk + off + (ntap == 9 ? tap : 0)] = s;
+  if (n < nstore && k < kstore) out[(size_t)n * ldn + (size_t)k * ldk + off + (ntap == 9 ? tap : 0)] = s;
 }
 
 // number of row splits: enough workgroups to fill the GPU, each split a multiple of 64 rows
@@ -250,7 +250,7 @@ hipError_t launch_wgrad(int dtype, const WgradArgs& a, hipStream_t s) {
     rows = kWgGroups;
   }
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a.partial, a.out, a.N, a.K,
-                     a.ntap, rows, a.ldn, a.ldk, a.off);
+                     a.ntap, rows, a.ldn, a.ldk, a.off, a.nstore > 0 ? a.nstore : a.N, a.kstore > 0 ? a.kstore : a.K);
   return hipGetLastError();
 }
 
