@@ -25,9 +25,9 @@ EXPORTS = [
     "llie_profile_begin", "llie_profile_end", "llie_enhance_workspace_bytes",
     "llie_preprocess_u8", "llie_postprocess_u8", "llie_profile_report", "llie_pw_gemm", "llie_pw_gemm_tile_rows", "llie_dwconv3x3", "llie_dwconv3x3_tiles", "llie_tune",
     "llie_grad_numel", "llie_param_grad_offset", "llie_train_workspace_bytes", "llie_unet_train_forward",
-    "llie_unet_backward", "llie_module_backward", "llie_load_all",
+    "llie_unet_backward", "llie_module_backward", "llie_load_all", "llie_profile_dump",
 ]
-K_GEMM, K_DW, K_CONV3, K_SE = 1, 2, 4, 8
+K_GEMM, K_DW, K_CONV3, K_SE, K_OTHER = 1, 2, 4, 8, 16
 
 
 class GemmSeg(C.Structure):
@@ -111,6 +111,7 @@ def lib() -> C.CDLL:
     L.llie_unet_backward.argtypes = [vp, vp, vp, ci, vp, i64, vp]
     L.llie_module_backward.argtypes = [vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, vp, i64, vp]
     L.llie_profile_report.argtypes = [vp, C.c_char_p, C.c_size_t]
+    L.llie_profile_dump.argtypes = [vp, C.c_char_p, C.c_size_t]
     L.llie_profile_begin.argtypes = [vp, ci]
     L.llie_profile_end.argtypes = [vp, ci, C.POINTER(C.c_double), C.POINTER(i64), C.POINTER(i64)]
     _lib = L
@@ -228,6 +229,16 @@ class Handle:
         for line in buf.value.decode().splitlines():
             name, ms, n, b = line.split("\t")
             out[name] = (float(ms), int(n), int(b))
+        return out
+
+    def profile_dump(self):
+        """-> [(class, kernel name, operator tag, device ms, algorithmic bytes)] of every recorded launch, in launch order."""
+        buf = C.create_string_buffer(1 << 21)
+        check(self._L.llie_profile_dump(self.h, buf, len(buf)), "profile_dump")
+        out = []
+        for line in buf.value.decode().splitlines():
+            cls, name, tag, ms, b = line.split("\t")
+            out.append((int(cls), name, tag, float(ms), int(b)))
         return out
 
     def profile_end(self, kernel_class: int):

@@ -73,6 +73,15 @@ __device__ __forceinline__ float apply_act(float x, int act) {
   return x;
 }
 
+// acc += w * f with w and f the LOW / HIGH f16 halves of two packed registers and an fp32 accumulator: one
+// v_fma_mix_f32, no separate conversions.
+__device__ __forceinline__ void fma_mix_lo(float& acc, uint32_t w2, uint32_t f2) {
+  asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,1,0]" : "+v"(acc) : "v"(w2), "v"(f2));
+}
+__device__ __forceinline__ void fma_mix_hi(float& acc, uint32_t w2, uint32_t f2) {
+  asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,1,0]" : "+v"(acc) : "v"(w2), "v"(f2));
+}
+
 // ---------------------------------------------------------------------------------------------
 // Wavefront (64-lane) reductions by xor-shuffle.
 __device__ __forceinline__ float wave_sum(float v) {

@@ -208,7 +208,7 @@ struct llie_ctx {
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   // per-kernel-class HIP-event profiling (llie_profile_begin / llie_profile_end)
   int prof_mask = 0;
-  struct ProfRec { int cls; int64_t bytes; hipEvent_t e0, e1; const char* name; };
+  struct ProfRec { int cls; int64_t bytes; hipEvent_t e0, e1; const char* name; char tag[56]; };
   std::vector<ProfRec> prof;
   std::vector<hipEvent_t> event_pool;
   hipEvent_t get_event() {
@@ -514,6 +514,9 @@ int build_module(llie_ctx* c) {
 // small@256 B=32 fp16; K1 without stores only drops 5.0 -> 4.6 ms), so it is opt-in: LLIE_DWX=1 or
 // llie_tune("dwx", 1).  See DESIGN.md section 8.
 bool g_use_dwx = getenv("LLIE_DWX") != nullptr;
+// Recompute form, second generation (irbx.hip: statistics-only expand + tile-fused expand/depthwise): default for the
+// inference path of 2-byte engines wherever irbx_supported(); llie_tune("irbx", 0) restores the unfused pair.
+int g_use_irbx = getenv("LLIE_NO_IRBX") ? 0 : 1;
 // Backward pass: run the weight-gradient kernels on a side stream next to the activation-gradient chain
 // (llie_tune("bwd_async", 0) puts everything back on the caller's stream).
 int g_bwd_async = 1;
@@ -522,6 +525,9 @@ int g_bwd_async = 1;
 // make the per-kernel durations that bench.py and rocprofv3 report (the roofline evidence) a function of the overlap
 // rather than of the kernel -- opt in with llie_tune("enhance_split", 1) when only throughput matters.
 int g_enhance_split = 0;
+// Captured graphs bake in the kernel choices of the moment: every llie_tune call starts a new epoch of the graph cache.
+int g_tune_epoch = 0;
+int tune_epoch() { return g_tune_epoch; }
 
 struct Run {
   llie_ctx* c;
@@ -533,6 +539,7 @@ struct Run {
   int dt;
   hipError_t err = hipSuccess;
   Tape* tape = nullptr;  // non-null: training forward -- nothing is released, every operator is recorded
+  char tag[56] = "";     // label of the operator being launched (llie_profile_dump)
   void rel(size_t off) { if (!tape) ar->free(off); }
 
   template <typename T = void> T* wptr(size_t off) const { return reinterpret_cast<T*>(c->blob + off); }
@@ -540,14 +547,15 @@ struct Run {
   void chk(hipError_t e) { if (e != hipSuccess && err == hipSuccess) err = e; }
   size_t es() const { return elem_size(dt); }
   // launch `f` bracketed by HIP events on the launch stream when its class is being profiled
-  template <typename F> void timed(int cls, int64_t bytes, F&& f) {
+  template <typename F> void timed(int cls, int64_t bytes, F&& f, const char* nm = nullptr) {
     if (!(c->prof_mask & cls) || c->prof.size() >= 8192) { chk(f()); return; }
-    llie_ctx::ProfRec r{cls, bytes, c->get_event(), c->get_event(), ""};
+    llie_ctx::ProfRec r{cls, bytes, c->get_event(), c->get_event(), "", {0}};
+    snprintf(r.tag, sizeof r.tag, "%s", tag);
     if (!r.e0 || !r.e1) { chk(f()); return; }
     chk(hipEventRecord(r.e0, s));
     chk(f());
     chk(hipEventRecord(r.e1, s));
-    r.name = last_kernel();  // static storage: launchers pass string literals / function-local statics
+    r.name = nm ? nm : last_kernel();  // static storage: launchers pass string literals / function-local statics
     c->prof.push_back(r);
   }
 
@@ -589,7 +597,7 @@ struct Run {
     a.film = film; a.film_stride = film_stride; a.eps = 1e-5f;
     a.as = p<float>(as); a.ab = p<float>(ab); a.B = B;
     if (tape && rec) { a.mean_out = p<float>(mo); a.rstd_out = p<float>(ro); }
-    chk(launch_gn_finalize(a, s));
+    timed(LLIE_K_OTHER, (int64_t)B * C * 8, [&] { return launch_gn_finalize(a, s); }, "gn_finalize_kernel");
   }
 
   // InvertedResidualBlock.forward (efficient_unet.py:203-236) as 7 launches.
@@ -598,16 +606,25 @@ struct Run {
     const int BM = pw_gemm_tile_rows(P);
     size_t as1, ab1;
     IrbRec rec{};
+    snprintf(tag, sizeof tag, "irb P=%d %d->%d hid=%d", P, w.cin, w.cout, w.hid);
     gn(x0, x1, w.n1g, w.n1b, nullptr, 0, as1, ab1, &rec.n1);
     // Recompute form (2-byte T, narrow inputs): K1 only produces h1's statistics and the fused
     // expand+depthwise kernel rebuilds h1 on the fly, so the 4x-expanded tensor never touches HBM.
-    const bool fused = !tape && g_use_dwx && dwx_supported(dt, w.cin, w.hid, H, W);
+    const bool fusedx = !tape && g_use_irbx && w.hid == w.hid_r && w.cin == w.cin_r &&
+                        irbx_supported(dt, w.cin, x0.C, w.hid, H, W);
+    const bool fused = !fusedx && !tape && g_use_dwx && dwx_supported(dt, w.cin, w.hid, H, W);
     // K1: expand with norm1 + ReLU6 prologue
     Tens h1;
-    h1.C = w.hid; h1.Cr = w.hid_r; h1.H = H; h1.W = W; h1.ntiles = P / BM; h1.valid = true;
-    h1.off = fused ? 0 : ar->alloc((size_t)B * P * w.hid * es());
+    h1.C = w.hid; h1.Cr = w.hid_r; h1.H = H; h1.W = W; h1.ntiles = fusedx ? P / irbx_stats_rows(P) : P / BM; h1.valid = true;
+    h1.off = (fused || fusedx) ? 0 : ar->alloc((size_t)B * P * w.hid * es());
     h1.slab = ar->alloc((size_t)B * h1.ntiles * 2 * w.hid * 4);
-    if (!dry) {
+    IrbxArgs xa{};
+    if (fusedx && !dry) {
+      xa.x0 = p(x0.off); xa.c0 = x0.C; xa.x1 = x1 ? p(x1->off) : nullptr; xa.c1 = x1 ? x1->C : 0;
+      xa.as1 = p<float>(as1); xa.ab1 = p<float>(ab1); xa.w1 = wptr(w.w_expand); xa.wd = wptr<float>(w.w_dw);
+      xa.stats = p<float>(h1.slab); xa.B = B; xa.H = H; xa.W = W; xa.Chid = w.hid;
+      timed(LLIE_K_GEMM, ((int64_t)M * w.cin + (int64_t)w.hid * w.cin) * (int64_t)es(), [&] { return launch_expand_stats(dt, xa, s); });
+    } else if (!dry) {
       GemmArgs g{};
       g.seg[0] = GemmSeg{p(x0.off), x0.C, p<float>(as1), p<float>(ab1), w.cin, ACT_RELU6};
       g.nseg = 1;
@@ -624,11 +641,14 @@ struct Run {
     size_t as2, ab2;
     gn(h1, nullptr, w.n2g, w.n2b, film ? film + w.film_off : nullptr, film_stride, as2, ab2, &rec.n2);
     // K2: depthwise with affine + ReLU6 prologue and SE pool partials
-    const int dnt = dwconv_ntiles(H, W);
+    const int dnt = fusedx ? irbx_pool_tiles(H, W) : dwconv_ntiles(H, W);
     const size_t h2 = ar->alloc((size_t)M * w.hid * es());
     const size_t pool = ar->alloc((size_t)B * dnt * w.hid * 4);
     if (!dry) {
-      if (fused) {
+      if (fusedx) {
+        xa.as2 = p<float>(as2); xa.ab2 = p<float>(ab2); xa.out = p(h2); xa.pool = p<float>(pool);
+        timed(LLIE_K_DW, (int64_t)M * (w.cin + w.hid) * (int64_t)es(), [&] { return launch_expand_dw(dt, xa, s); });
+      } else if (fused) {
         DwxArgs d{};
         d.x0 = p(x0.off); d.c0 = x0.C; d.x1 = x1 ? p(x1->off) : nullptr; d.c1 = x1 ? x1->C : 0;
         d.as1 = p<float>(as1); d.ab1 = p<float>(ab1); d.w1 = wptr(w.w_expand);
@@ -643,7 +663,7 @@ struct Run {
       }
     }
     rel(as1); rel(ab1);
-    if (!fused) rel(h1.off);
+    if (!fused && !fusedx) rel(h1.off);
     rel(h1.slab);
     rel(as2); rel(ab2);
     // SE MLP
@@ -697,6 +717,7 @@ struct Run {
     const int BM = pw_gemm_tile_rows(N);
     size_t as, ab;
     AttnRec rec{};
+    snprintf(tag, sizeof tag, "attn N=%d C=%d", N, x.C);
     gn(x, nullptr, w.ng, w.nb, nullptr, 0, as, ab, &rec.n1);
     const size_t qkv = ar->alloc((size_t)M * 3 * w.inner * es());
     if (!dry) {
@@ -704,7 +725,7 @@ struct Run {
       g.seg[0] = GemmSeg{p(x.off), x.C, p<float>(as), p<float>(ab), x.C, ACT_NONE};
       g.nseg = 1; g.w = wptr(w.w_qkv); g.out = p(qkv);
       g.M = M; g.N = 3 * w.inner; g.K = x.C; g.P = N;
-      chk(launch_pw_gemm(dt, g, s));
+      timed(LLIE_K_GEMM, ((int64_t)M * (x.C + 3 * w.inner) + 3LL * w.inner * x.C) * (int64_t)es(), [&] { return launch_pw_gemm(dt, g, s); });
     }
     rel(as); rel(ab);
     const int nsplit = linattn_nsplit(N);
@@ -713,8 +734,8 @@ struct Run {
     if (!dry) {
       AttnArgs a{};
       a.qkv = p(qkv); a.B = B; a.N = N; a.heads = w.heads; a.kv = p<float>(kv); a.out = p(ao); a.nsplit = nsplit;
-      chk(launch_linattn_kv(dt, a, s));
-      chk(launch_linattn_out(dt, a, s));
+      timed(LLIE_K_OTHER, (int64_t)M * 2 * w.inner * (int64_t)es(), [&] { return launch_linattn_kv(dt, a, s); }, "linattn_kv_kernel");
+      timed(LLIE_K_OTHER, (int64_t)M * 2 * w.inner * (int64_t)es(), [&] { return launch_linattn_out(dt, a, s); }, "linattn_out_kernel");
     }
     rel(qkv); rel(kv);
     Tens tmp = new_tens(x.C, H, W, N / BM);
@@ -723,7 +744,7 @@ struct Run {
       g.seg[0] = GemmSeg{p(ao), w.inner, nullptr, nullptr, 0, ACT_NONE};
       g.nseg = 1; g.w = wptr(w.w_out); g.out = p(tmp.off); g.stats = p<float>(tmp.slab);
       g.M = M; g.N = x.C; g.K = w.inner; g.P = N;
-      chk(launch_pw_gemm(dt, g, s));
+      timed(LLIE_K_GEMM, ((int64_t)M * (x.C + w.inner) + (int64_t)w.inner * x.C) * (int64_t)es(), [&] { return launch_pw_gemm(dt, g, s); });
     }
     rel(ao);
     size_t as2, ab2;
@@ -733,7 +754,7 @@ struct Run {
       AffineAddArgs a{};
       a.x = p(tmp.off); a.as = p<float>(as2); a.ab = p<float>(ab2); a.res = p(x.off); a.y = p(y.off);
       a.stats = p<float>(y.slab); a.M = M; a.C = x.C; a.P = N;
-      chk(launch_affine_add(dt, a, s));
+      timed(LLIE_K_OTHER, 3LL * M * x.C * (int64_t)es(), [&] { return launch_affine_add(dt, a, s); }, "affine_add_kernel");
     }
     free_tens(tmp);
     rel(as2); rel(ab2);
@@ -750,6 +771,7 @@ struct Run {
     const int Ho = mode == 0 ? x.H / 2 : x.H * 2, Wo = mode == 0 ? x.W / 2 : x.W * 2;
     Tens y = new_tens(w.c, Ho, Wo, conv3x3_ntiles(Ho, Wo), w.c_r);
     Tens u;
+    snprintf(tag, sizeof tag, "conv3 mode=%d C=%d %dx%d", mode, w.c, x.H, x.W);
     if (tape && mode == 1) {
       // training: keep the upsampled tensor (the weight gradient reads it) and run the plain stride-1 conv on it
       u.C = w.c; u.H = Ho; u.W = Wo; u.valid = true;
@@ -804,11 +826,12 @@ struct Run {
       ta.t = t; ta.rows = rows; ta.dim = g.base_channels; ta.freqs = wptr<float>(c->freqs); ta.T = T;
       ta.w1 = wptr<float>(c->t_w1); ta.b1 = wptr<float>(c->t_b1); ta.w3 = wptr<float>(c->t_w3); ta.b3 = wptr<float>(c->t_b3);
       ta.temb = p<float>(temb); ta.silu_temb = p<float>(stemb);
-      chk(launch_time_embed(ta, s));
+      snprintf(tag, sizeof tag, "time");
+      timed(LLIE_K_OTHER, 0, [&] { return launch_time_embed(ta, s); }, "time_embed_kernel");
       FilmArgs fa{};
       fa.silu_temb = p<float>(stemb); fa.rows = rows; fa.T = T; fa.wf = wptr<float>(c->film_w); fa.bf = wptr<float>(c->film_b);
       fa.film = p<float>(film); fa.F = F;
-      chk(launch_film(fa, s));
+      timed(LLIE_K_OTHER, (int64_t)F * T * 4, [&] { return launch_film(fa, s); }, "film_kernel");
     }
     const float* filmp = p<float>(film);
     const int64_t fstride = uniform_t ? 0 : F;
@@ -821,7 +844,8 @@ struct Run {
       a.w = wptr<float>(c->init_w); a.bias = wptr<float>(c->init_b); a.out = p(h.off); a.stats = p<float>(h.slab);
       a.wp = dt != LLIE_F32 ? wptr(c->init_wp) : nullptr;
       a.B = B; a.H = S; a.W = S; a.Cout = c->channels[0];
-      chk(launch_init_conv(dt, a, s));
+      snprintf(tag, sizeof tag, "init_conv");
+      timed(LLIE_K_OTHER, (int64_t)B * S * S * (g.in_channels * 4 + c->channels[0] * (int64_t)es()), [&] { return launch_init_conv(dt, a, s); }, "init_conv_kernel");
     }
     if (tape) {
       tape->temb = temb; tape->stemb = stemb; tape->film = film; tape->h0 = h;
@@ -847,6 +871,7 @@ struct Run {
     }
     size_t as, ab;
     GnRec finrec{};
+    snprintf(tag, sizeof tag, "final_norm");
     gn(h, nullptr, c->fin_g, c->fin_b, nullptr, 0, as, ab, &finrec);
     if (tape) { tape->fin = finrec; tape->hlast = h; }
     if (!dry) {
@@ -857,7 +882,8 @@ struct Run {
       if (fs) {
         a.fuse_step = 1; a.coef = fs->coef; a.sample = lat; a.noise = fs->noise; a.prev = fs->prev; a.clamped = fs->clamped;
       }
-      chk(launch_final_conv(dt, a, s));
+      snprintf(tag, sizeof tag, "final_conv");
+      timed(LLIE_K_OTHER, (int64_t)B * S * S * (c->channels[0] * (int64_t)es() + 3 * 4 * (fs ? 4 : 1)), [&] { return launch_final_conv(dt, a, s); }, "final_conv_kernel");
     }
     free_tens(h);
     rel(as); rel(ab);
@@ -1870,8 +1896,8 @@ int llie_enhance(llie_ctx* c, const float* low, const float* noise, const int64_
 
   std::string key(reinterpret_cast<const char*>(coefs), sizeof(llie_step_coef) * steps);
   char tail[128];
-  snprintf(tail, sizeof tail, "|%d|%d|%d|%d|%p|%lld|%d", batch, steps, inter ? 1 : 0, preds ? 1 : 0, ws, (long long)ws_bytes,
-           g_enhance_split);
+  snprintf(tail, sizeof tail, "|%d|%d|%d|%d|%p|%lld|%d|%d", batch, steps, inter ? 1 : 0, preds ? 1 : 0, ws, (long long)ws_bytes,
+           g_enhance_split, tune_epoch());
   key += tail;
   llie_ctx::GraphEntry& ge = c->graphs[key];
   if (!ge.seen) {
@@ -1993,9 +2019,13 @@ int llie_pw_gemm_tile_rows(int P) { return pw_gemm_tile_rows(P); }
 
 int llie_tune(const char* knob, int value) {
   if (!knob) return LLIE_ERR_ARG;
+  ++g_tune_epoch;
   if (!strcmp(knob, "gemm_bk")) { pw_gemm_force_bk(value); return LLIE_OK; }
   if (!strcmp(knob, "gemm_v2")) { pw_gemm_use_v2(value); return LLIE_OK; }
   if (!strcmp(knob, "dwx")) { g_use_dwx = value != 0; return LLIE_OK; }
+  if (!strcmp(knob, "irbx")) { g_use_irbx = value != 0; return LLIE_OK; }
+  if (!strcmp(knob, "irbx_dbuf")) { irbx_tune(value, 0); return LLIE_OK; }
+  if (!strcmp(knob, "irbx_tiles")) { irbx_tune(-1, value); return LLIE_OK; }
   if (!strcmp(knob, "gemm_ablate")) { pw_gemm_debug(value); return LLIE_OK; }
   if (!strcmp(knob, "dw_ablate")) { dwconv_debug(value); return LLIE_OK; }
   if (!strcmp(knob, "dw_swap")) { dwconv_swap(value); return LLIE_OK; }
@@ -2052,6 +2082,25 @@ int llie_profile_report(llie_ctx* c, char* buf, size_t cap) {
     out += line;
   }
   if (out.size() + 1 > cap) { set_err("profile report buffer too small"); return LLIE_ERR_ARG; }
+  memcpy(buf, out.c_str(), out.size() + 1);
+  return LLIE_OK;
+}
+
+// Every recorded launch, in launch order: "class\tkernel\ttag\tms\talgorithmic_bytes\n" (tools/gpu_layers.py).
+int llie_profile_dump(llie_ctx* c, char* buf, size_t cap) {
+  if (!c || !buf || cap < 2) return LLIE_ERR_ARG;
+  c->prof_mask = 0;
+  std::string out;
+  char line[640];
+  for (auto& r : c->prof) {
+    hipError_t e = hipEventSynchronize(r.e1);
+    float t = 0.f;
+    if (e == hipSuccess) e = hipEventElapsedTime(&t, r.e0, r.e1);
+    if (e != hipSuccess) { set_err("profile: %s", hipGetErrorString(e)); return (int)e; }
+    snprintf(line, sizeof line, "%d\t%s\t%s\t%.6f\t%lld\n", r.cls, r.name ? r.name : "?", r.tag, t, (long long)r.bytes);
+    out += line;
+  }
+  if (out.size() + 1 > cap) { set_err("profile dump buffer too small"); return LLIE_ERR_ARG; }
   memcpy(buf, out.c_str(), out.size() + 1);
   return LLIE_OK;
 }

@@ -1,0 +1,482 @@
+// Front half of an InvertedResidualBlock in its "recompute" form for gfx950 (2-byte compute types):
+//
+//   h2 = dw3x3( relu6( aff2( W1 . relu6( aff1(x) ) ) ) )      aff1 = GroupNorm-1, aff2 = GroupNorm-2 + FiLM
+//   (efficient_unet.py:207-220: norm1, ReLU6, expand, norm2, FiLM, ReLU6, depthwise)
+//
+// The 4x-expanded tensor h1 = W1 . a is the largest object of the network.  The unfused path writes it (pw_gemm)
+// and reads it back (dwconv3x3); here it never reaches HBM (SURVEY.md 8d "recompute variant", 3Cin + 2Chid + Cout
+// elements per pixel instead of 2Cin + 4Chid + Cout):
+//
+//   expand_stats_kernel  reads x once and produces only h1's per-channel (sum, sum of squares) slab for GroupNorm-2:
+//                        lanes load their MFMA operand slices of x straight from HBM (16 B per lane), the 32x32
+//                        accumulators are squared / summed in registers and never stored;
+//   expand_dw_kernel     a workgroup owns an 8 x 16 pixel tile: it rebuilds h1 on the 10 x 18 halo tile with MFMA
+//                        (weights = A operand, pixels = B operand, so a lane ends up with runs of channels of ONE
+//                        pixel), applies aff2 + ReLU6 (+ zero padding) to the accumulators, parks the tile in LDS as
+//                        [pixel][64 channels] and runs the depthwise 3x3 from there, 64 hidden channels at a time;
+//                        the x tile is loaded once per tile (next tile prefetched) and reused by every channel chunk.
+//
+// Both kernels write fixed per-tile partial sums (no atomics), so results stay bitwise independent of the batch.
+#include <string>
+#include <type_traits>
+
+#include "common.h"
+#include "kernels.h"
+
+namespace llie {
+
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+template <typename T>
+__device__ __forceinline__ f32x16 mfma16(typename Elem<T>::vec_t a, typename Elem<T>::vec_t b, f32x16 c) {
+  if constexpr (std::is_same<T, half_t>::value) return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
+// a' = relu6(a * s + b) on one 16-byte operand slice (8 channels); sc / sh point at the slice's 8 scale / shift
+// values in an LDS table (16-byte aligned), read at use so that they do not occupy registers across the kernel
+template <typename T>
+__device__ __forceinline__ typename Elem<T>::vec_t activate8(typename Elem<T>::vec_t v, const float* sc, const float* sh) {
+  float f[8];
+  vec_to_f32<T>(v, f);
+  const f32x4 s0 = *reinterpret_cast<const f32x4*>(sc), s1 = *reinterpret_cast<const f32x4*>(sc + 4);
+  const f32x4 b0 = *reinterpret_cast<const f32x4*>(sh), b1 = *reinterpret_cast<const f32x4*>(sh + 4);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    f[e] = relu6f(f[e] * s0[e] + b0[e]);
+    f[4 + e] = relu6f(f[4 + e] * s1[e] + b1[e]);
+  }
+  return f32_to_vec<T>(f);
+}
+
+// ---------------------------------------------------------------------------------------------
+// (1) statistics of h1 = W1 . relu6(aff1(x)) without storing it.
+//   grid (P / RP, 1, B); 4 waves = PS pixel groups x NS channel groups; a wave owns NBW = Chid / 32 / NS
+//   32-channel blocks (their weight slices stay in registers) and RP / PS pixels.
+//   MFMA roles: A = pixels (rows), B = weights (columns): a lane holds 16 pixels of ONE channel, so the
+//   per-channel sums are plain register adds.
+template <typename T, int KS, int NBW, int NS>
+__global__ void __launch_bounds__(256) expand_stats_kernel(const IrbxArgs a, const int RP) {
+  constexpr int K = 16 * KS, PS = 4 / NS;
+  typedef typename Elem<T>::vec_t vec_t;
+  __shared__ float red[4][2][NBW * 32];
+  __shared__ __align__(16) float aff1[2][K];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n = lane & 31, h = lane >> 5;
+  const int pg = wave % PS, ng = wave / PS;
+  const int b = blockIdx.z, tile = blockIdx.x;
+  const int P = a.H * a.W;
+  const T* x0 = reinterpret_cast<const T*>(a.x0) + (size_t)b * P * a.c0;
+  const T* x1 = a.x1 ? reinterpret_cast<const T*>(a.x1) + (size_t)b * P * a.c1 : nullptr;
+  const T* w1 = reinterpret_cast<const T*>(a.w1);
+
+  vec_t wf[NBW][KS];
+#pragma unroll
+  for (int j = 0; j < NBW; ++j)
+#pragma unroll
+    for (int s = 0; s < KS; ++s) wf[j][s] = ld_vec<T>(w1 + (size_t)((ng * NBW + j) * 32 + n) * K + 16 * s + 8 * h);
+  for (int i = tid; i < K; i += 256) {
+    aff1[0][i] = a.as1[(size_t)b * K + i];
+    aff1[1][i] = a.ab1[(size_t)b * K + i];
+  }
+  __syncthreads();
+  float s1[NBW], s2[NBW];
+#pragma unroll
+  for (int j = 0; j < NBW; ++j) s1[j] = s2[j] = 0.f;
+
+  const int nblk = RP / PS / 32;  // 32-pixel blocks of this wave
+  const int p_first = tile * RP + pg * (RP / PS);
+  auto load = [&](int blk, vec_t (&v)[KS]) {
+    const size_t pix = (size_t)p_first + blk * 32 + n;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const int k = 16 * s + 8 * h;
+      v[s] = k < a.c0 ? ld_vec<T>(x0 + pix * a.c0 + k) : ld_vec<T>(x1 + pix * a.c1 + (k - a.c0));
+    }
+  };
+  vec_t cur[KS], nxt[KS];
+  load(0, cur);
+  for (int blk = 0; blk < nblk; ++blk) {
+    if (blk + 1 < nblk) load(blk + 1, nxt);
+    vec_t af[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) af[s] = activate8<T>(cur[s], &aff1[0][16 * s + 8 * h], &aff1[1][16 * s + 8 * h]);
+#pragma unroll
+    for (int j = 0; j < NBW; ++j) {
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+      for (int s = 0; s < KS; ++s) acc = mfma16<T>(af[s], wf[j][s], acc);
+      float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        t1 += acc[r];
+        t2 += acc[r] * acc[r];
+      }
+      s1[j] += t1;
+      s2[j] += t2;
+    }
+#pragma unroll
+    for (int s = 0; s < KS; ++s) cur[s] = nxt[s];
+  }
+  // lane halves hold different pixel rows of the same channel; then the PS pixel groups, in wave order
+#pragma unroll
+  for (int j = 0; j < NBW; ++j) {
+    s1[j] += __shfl_xor(s1[j], 32, 64);
+    s2[j] += __shfl_xor(s2[j], 32, 64);
+    if (h == 0) {
+      red[wave][0][j * 32 + n] = s1[j];
+      red[wave][1][j * 32 + n] = s2[j];
+    }
+  }
+  __syncthreads();
+  const int ntiles = P / RP;
+  for (int i = tid; i < 2 * a.Chid; i += 256) {
+    const int which = i / a.Chid, c = i % a.Chid;
+    const int g = c / (NBW * 32), cc = c % (NBW * 32);
+    float t = 0.f;
+#pragma unroll
+    for (int q = 0; q < PS; ++q) t += red[g * PS + q][which][cc];
+    a.stats[((size_t)(b * ntiles + tile) * 2 + which) * a.Chid + c] = t;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// (2) fused expand + norm2 / FiLM / ReLU6 + depthwise 3x3 + SE pool partials.
+constexpr int kXT_H = 8, kXT_W = 16;                 // output tile
+constexpr int kXH_W = kXT_W + 2, kXH_H = kXT_H + 2;  // halo tile 10 x 18 = 180 pixels -> 6 blocks of 32
+constexpr int kXNPX = kXH_W * kXH_H;
+constexpr int kXNPB = 6;
+
+// LDS image of the activated h1 tile: [pixel q][8 slots of 16 B = 64 channels], slot' = slot ^ (q & 3).
+// The 128-byte pixel pitch keeps the depthwise phase's ds_read_b128 conflict free (16-lane groups of gfx950);
+// the xor spreads the epilogue's ds_write_b128 (8 consecutive pixels, same slot) over 4 slots.
+__device__ __forceinline__ int xh_off(int q, int slot) { return q * 128 + ((slot ^ (q & 3)) << 4); }
+
+template <typename T, int KS, bool DBUF>
+__global__ void __launch_bounds__(256, 2) expand_dw_kernel(const IrbxArgs a, const int tiles_per_wg, const int chunks_per_wg) {
+  constexpr int K = 16 * KS;
+  constexpr int XP = (K + 8) * 2;                        // sX pixel pitch in bytes (80 / 144 / 208 / 272: conflict-free ds_read_b128)
+  constexpr int XV = kXNPX * 2 * KS;                     // 16-byte vectors of one x halo tile
+  constexpr int XPT = (XV + 255) / 256;                  // ... per thread
+  constexpr int SH_BYTES = kXNPB * 32 * 128;
+  typedef typename Elem<T>::vec_t vec_t;
+  extern __shared__ __align__(16) unsigned char smem[];
+  // [sH: (DBUF ? 2 : 1) x 192 x 128 B][sX: 192 x XP][wds: 9 x Chid T][aff2: 2 x Chid fp32][aff1: 2 x K fp32][red: 2 x 4 x 64 fp32]
+  unsigned char* sH = smem;
+  unsigned char* sX = smem + (DBUF ? 2 : 1) * SH_BYTES;
+  T* wds = reinterpret_cast<T*>(sX + kXNPB * 32 * XP);
+  float* aff2 = reinterpret_cast<float*>(wds + 9 * a.Chid);
+  float* aff1 = aff2 + 2 * a.Chid;
+  float* red = aff1 + 2 * K;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n = lane & 31, h = lane >> 5;
+  const int chb = wave & 1, pxg = wave >> 1;
+  const int b = blockIdx.z;
+  const int tiles_x = a.W / kXT_W;
+  const int P = a.H * a.W;
+  const T* x0 = reinterpret_cast<const T*>(a.x0) + (size_t)b * P * a.c0;
+  const T* x1 = a.x1 ? reinterpret_cast<const T*>(a.x1) + (size_t)b * P * a.c1 : nullptr;
+  const T* w1 = reinterpret_cast<const T*>(a.w1);
+  T* out = reinterpret_cast<T*>(a.out) + (size_t)b * P * a.Chid;
+  const int chunk0 = blockIdx.y * chunks_per_wg;
+  const int nchunks_all = a.Chid / 64;
+  const int chunk1 = chunk0 + chunks_per_wg < nchunks_all ? chunk0 + chunks_per_wg : nchunks_all;
+
+  // ---- per-workgroup constants: depthwise weights (packed T), affine tables of this image
+  for (int i = tid; i < 9 * a.Chid; i += 256) wds[i] = (T)a.wd[i];
+  for (int i = tid; i < a.Chid; i += 256) {
+    aff2[i] = a.as2[(size_t)b * a.Chid + i];
+    aff2[a.Chid + i] = a.ab2[(size_t)b * a.Chid + i];
+  }
+  for (int i = tid; i < K; i += 256) {
+    aff1[i] = a.as1[(size_t)b * K + i];
+    aff1[K + i] = a.ab1[(size_t)b * K + i];
+  }
+  // pixels 180..191 of the last MFMA block do not exist: their operand rows stay zero
+  for (int i = tid; i < (kXNPB * 32 - kXNPX) * (XP / 16); i += 256)
+    *reinterpret_cast<u32x4*>(sX + kXNPX * XP + i * 16) = u32x4{0u, 0u, 0u, 0u};
+
+  // depthwise phase roles
+  const int cl = tid & 7, xl = tid >> 3, cx = xl & 15, rh = xl >> 4;
+
+  const int tile_first = blockIdx.x * tiles_per_wg;
+  const int ntiles_img = tiles_x * (a.H / kXT_H);
+  const int tile_last = tile_first + tiles_per_wg < ntiles_img ? tile_first + tiles_per_wg : ntiles_img;
+
+  // x halo tile: vector v = tid + j*256 -> pixel v / (2 KS), channel vector v % (2 KS)
+  vec_t raw[XPT];
+  auto load_tile = [&](int tile) {
+    const int ty = tile / tiles_x, tx = tile % tiles_x;
+#pragma unroll
+    for (int j = 0; j < XPT; ++j) {
+      const int v = tid + j * 256;
+      const int q = v / (2 * KS), k = (v % (2 * KS)) * 8;
+      const int gy = ty * kXT_H - 1 + q / kXH_W, gx = tx * kXT_W - 1 + q % kXH_W;
+      if ((XV % 256 == 0 || v < XV) && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {
+        const size_t pix = (size_t)gy * a.W + gx;
+        raw[j] = k < a.c0 ? ld_vec<T>(x0 + pix * a.c0 + k) : ld_vec<T>(x1 + pix * a.c1 + (k - a.c0));
+      } else {
+        raw[j] = vec_t{};  // outside the image: h1 is forced to zero there (ok[] below), the value is irrelevant
+      }
+    }
+  };
+  if (tile_first < tile_last) load_tile(tile_first);
+  __syncthreads();  // constants staged
+
+  int par = 0;  // sH / red buffer parity (DBUF)
+  int pend_tile = -1, pend_chunk = 0, pend_par = 0;  // pool partial waiting for its cross-wave sum
+  auto flush_pool = [&]() {  // after a barrier that follows the depthwise phase which wrote red[pend_par]
+    if (pend_tile >= 0 && tid < 64) {
+      const float* r = red + pend_par * 256;
+      const float t = r[tid] + r[64 + tid] + r[128 + tid] + r[192 + tid];
+      a.pool[((size_t)b * ntiles_img + pend_tile) * a.Chid + pend_chunk * 64 + tid] = t;
+    }
+    pend_tile = -1;
+  };
+
+  for (int tile = tile_first; tile < tile_last; ++tile) {
+    const int ty = tile / tiles_x, tx = tile % tiles_x;
+    const int y0 = ty * kXT_H, x0p = tx * kXT_W;
+    // ---- activate this tile's x (norm1 + ReLU6) into sX, prefetch the next tile.  Every wave is past the last
+    // MFMA phase of the previous tile here (the barrier that follows it), so sX is free.
+#pragma unroll
+    for (int j = 0; j < XPT; ++j) {
+      const int v = tid + j * 256;
+      if (XV % 256 == 0 || v < XV) {
+        const int q = v / (2 * KS), k = (v % (2 * KS)) * 8;
+        *reinterpret_cast<vec_t*>(sX + q * XP + k * 2) = activate8<T>(raw[j], aff1 + k, aff1 + K + k);
+      }
+    }
+    if (tile + 1 < tile_last) load_tile(tile + 1);
+    // validity of this lane's three halo pixels (zero padding of the depthwise input)
+    bool ok[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int q = (pxg * 3 + i) * 32 + n;
+      const int gy = y0 - 1 + q / kXH_W, gx = x0p - 1 + q % kXH_W;
+      ok[i] = q < kXNPX && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+    }
+    __syncthreads();
+    if (!DBUF) flush_pool();
+
+    for (int chunk = chunk0; chunk < chunk1; ++chunk) {
+      unsigned char* buf = sH + (DBUF ? par * SH_BYTES : 0);
+      if (!DBUF && chunk > chunk0) {
+        __syncthreads();  // previous depthwise phase done with sH
+        flush_pool();
+      }
+      // ---- MFMA: h1^T block (32 channels x 32 pixels) x 3 pixel blocks
+      const int ch0 = chunk * 64 + chb * 32;
+      vec_t wf[KS];
+#pragma unroll
+      for (int s = 0; s < KS; ++s) wf[s] = ld_vec<T>(w1 + (size_t)(ch0 + n) * K + 16 * s + 8 * h);
+      // aff2 of this lane's 16 accumulator channels: ch0 + 8g + 4h + e
+      f32x4 sc2[4], sh2[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        sc2[g] = *reinterpret_cast<const f32x4*>(aff2 + ch0 + 8 * g + 4 * h);
+        sh2[g] = *reinterpret_cast<const f32x4*>(aff2 + a.Chid + ch0 + 8 * g + 4 * h);
+      }
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        const int q = (pxg * 3 + i) * 32 + n;
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
+          acc = mfma16<T>(wf[s], *reinterpret_cast<const vec_t*>(sX + q * XP + (16 * s + 8 * h) * 2), acc);
+        // epilogue: aff2 + ReLU6, zero outside the image (the conv's padding), pack, exchange lane halves so
+        // that each lane owns 8 consecutive channels, two ds_write_b128
+        uint32_t pk[4][2];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          typedef T t2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            t2 o;
+            const float v0 = relu6f(acc[4 * g + 2 * j] * sc2[g][2 * j] + sh2[g][2 * j]);
+            const float v1 = relu6f(acc[4 * g + 2 * j + 1] * sc2[g][2 * j + 1] + sh2[g][2 * j + 1]);
+            o[0] = (T)v0;
+            o[1] = (T)v1;
+            pk[g][j] = ok[i] ? *reinterpret_cast<uint32_t*>(&o) : 0u;
+          }
+        }
+        u32x4 lo, hi2;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const u32x2 r02 = __builtin_amdgcn_permlane32_swap(pk[0][j], pk[2][j], false, false);
+          const u32x2 r13 = __builtin_amdgcn_permlane32_swap(pk[1][j], pk[3][j], false, false);
+          lo[j] = r02[0]; lo[2 + j] = r02[1];    // h=0: channels 0..7 of the block; h=1: channels 16..23
+          hi2[j] = r13[0]; hi2[2 + j] = r13[1];  // h=0: channels 8..15;             h=1: channels 24..31
+        }
+        *reinterpret_cast<u32x4*>(buf + xh_off(q, chb * 4 + 2 * h)) = lo;
+        *reinterpret_cast<u32x4*>(buf + xh_off(q, chb * 4 + 2 * h + 1)) = hi2;
+      }
+      __syncthreads();
+      if (DBUF) flush_pool();
+      // ---- depthwise 3x3 on the LDS tile: thread = 8 channels x 4 output rows of one column
+      {
+        const int c8 = chunk * 64 + cl * 8;
+        vec_t w[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) w[t] = *reinterpret_cast<const vec_t*>(wds + t * a.Chid + c8);
+        float acc3[3][8], psum[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc3[0][e] = acc3[1][e] = acc3[2][e] = psum[e] = 0.f;
+        T* orow = out + ((size_t)(y0 + rh * 4) * a.W + x0p + cx) * a.Chid + c8;
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {  // halo rows rh*4 + r
+          const int qrow = (rh * 4 + r) * kXH_W + cx;
+          vec_t f[3];
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx) f[kx] = *reinterpret_cast<const vec_t*>(buf + xh_off(qrow + kx, cl));
+          float* a2 = acc3[(r + 1) % 3];  // ky = 2 -> output row r-2
+          float* a1 = acc3[(r + 2) % 3];  // ky = 1 -> output row r-1
+          float* a0 = acc3[r % 3];        // ky = 0 -> output row r
+          if constexpr (std::is_same<T, half_t>::value) {
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+              const u32x4 fq = reinterpret_cast<const u32x4&>(f[kx]);
+              const u32x4 w2 = reinterpret_cast<const u32x4&>(w[6 + kx]);
+              const u32x4 w1v = reinterpret_cast<const u32x4&>(w[3 + kx]);
+              const u32x4 w0 = reinterpret_cast<const u32x4&>(w[0 + kx]);
+#pragma unroll
+              for (int q4 = 0; q4 < 4; ++q4) {
+                if (r >= 2) { fma_mix_lo(a2[2 * q4], w2[q4], fq[q4]); fma_mix_hi(a2[2 * q4 + 1], w2[q4], fq[q4]); }
+                if (r >= 1 && r <= 4) { fma_mix_lo(a1[2 * q4], w1v[q4], fq[q4]); fma_mix_hi(a1[2 * q4 + 1], w1v[q4], fq[q4]); }
+                if (r <= 3) { fma_mix_lo(a0[2 * q4], w0[q4], fq[q4]); fma_mix_hi(a0[2 * q4 + 1], w0[q4], fq[q4]); }
+              }
+            }
+          } else {
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+              for (int e = 0; e < 8; ++e) {
+                if (r >= 2) a2[e] += (float)w[6 + kx][e] * (float)f[kx][e];
+                if (r >= 1 && r <= 4) a1[e] += (float)w[3 + kx][e] * (float)f[kx][e];
+                if (r <= 3) a0[e] += (float)w[0 + kx][e] * (float)f[kx][e];
+              }
+          }
+          if (r >= 2) {
+            vec_t ov = f32_to_vec<T>(a2);
+            st_vec<T>(orow + (size_t)(r - 2) * a.W * a.Chid, ov);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              psum[e] += (float)ov[e];
+              a2[e] = 0.f;
+            }
+          }
+        }
+        // SE pool partial of this (tile, chunk): lanes -> per-wave channel sums -> red[par][wave][64]
+        if (a.pool) {
+          pool_segment_flush<8>(psum, red + (DBUF ? par : 0) * 256 + wave * 64, lane);
+          pend_tile = tile; pend_chunk = chunk; pend_par = DBUF ? par : 0;
+        }
+      }
+      if (DBUF) par ^= 1;
+    }
+  }
+  if (a.pool) {
+    __syncthreads();
+    flush_pool();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+int irbx_stats_rows(int P);
+bool irbx_supported(int dtype, int Cin, int c0, int Chid, int H, int W) {
+  if (dtype != 1 && dtype != 2) return false;
+  if (Cin != 32 && Cin != 64 && Cin != 96) return false;  // Cin = 128: 92 KB of LDS = one workgroup per CU, not worth it
+  if (c0 % 16 || Chid != 4 * Cin) return false;
+  return W % kXT_W == 0 && H % kXT_H == 0 && (H * W) % irbx_stats_rows(H * W) == 0;
+}
+int irbx_pool_tiles(int H, int W) { return (H / kXT_H) * (W / kXT_W); }
+// pixels per statistics partial: fixed per image size (never a function of the batch: bitwise batch invariance)
+int irbx_stats_rows(int P) {
+  int rp = 128;  // a power of two in [128, 1024], about P / 64
+  while (rp < 1024 && rp * 2 * 64 <= P) rp *= 2;
+  return rp;
+}
+
+static int g_irbx_dbuf = 1, g_irbx_tiles = 4;
+void irbx_tune(int dbuf, int tiles_per_wg) {
+  if (dbuf >= 0) g_irbx_dbuf = dbuf;
+  if (tiles_per_wg > 0) g_irbx_tiles = tiles_per_wg;
+}
+
+template <typename T, int KS, int NBW, int NS>
+static hipError_t launch_stats_cfg(const IrbxArgs& a, hipStream_t s) {
+  const int P = a.H * a.W, RP = irbx_stats_rows(P);
+  static const std::string name = std::string("expand_stats_kernel<") + TypeName<T>::value + ", " + std::to_string(KS) + ", " +
+                                  std::to_string(NBW) + ", " + std::to_string(NS) + ">";
+  note_kernel(name.c_str());
+  hipLaunchKernelGGL((expand_stats_kernel<T, KS, NBW, NS>), dim3(P / RP, 1, a.B), dim3(256), 0, s, a, RP);
+  return hipGetLastError();
+}
+template <typename T>
+static hipError_t launch_stats_t(const IrbxArgs& a, hipStream_t s) {
+  const int Cin = a.c0 + a.c1;
+  if (Cin == 32 && a.Chid == 128) return launch_stats_cfg<T, 2, 4, 1>(a, s);
+  if (Cin == 64 && a.Chid == 256) return launch_stats_cfg<T, 4, 4, 2>(a, s);
+  if (Cin == 96 && a.Chid == 384) return launch_stats_cfg<T, 6, 3, 4>(a, s);
+  return hipErrorInvalidValue;
+}
+hipError_t launch_expand_stats(int dtype, const IrbxArgs& a, hipStream_t s) {
+  if (!irbx_supported(dtype, a.c0 + a.c1, a.c0, a.Chid, a.H, a.W) || (a.c1 && !a.x1) || !a.stats) return hipErrorInvalidValue;
+  if (a.Chid != 4 * (a.c0 + a.c1)) return hipErrorInvalidValue;
+  return dtype == 1 ? launch_stats_t<half_t>(a, s) : launch_stats_t<bf16_t>(a, s);
+}
+
+template <typename T, int KS, bool DBUF>
+static hipError_t launch_dw_cfg(const IrbxArgs& a, hipStream_t s) {
+  const size_t lds = (size_t)(DBUF ? 2 : 1) * kXNPB * 32 * 128 + (size_t)kXNPB * 32 * (16 * KS + 8) * 2 + (size_t)9 * a.Chid * 2 +
+                     (size_t)2 * a.Chid * 4 + (size_t)2 * 16 * KS * 4 + 2 * 256 * 4;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&expand_dw_kernel<T, KS, DBUF>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    if (e != hipSuccess) return e;
+    attr_done = true;
+  }
+  const int ntiles = irbx_pool_tiles(a.H, a.W), nchunks = a.Chid / 64;
+  // tiles per workgroup: a run along x (neighbouring halo columns hit L1), as long as the launch keeps >= 2048 workgroups
+  int tpw = g_irbx_tiles;
+  while (tpw > 1 && ((a.W / kXT_W) % tpw || (long)(ntiles / tpw) * a.B < 2048)) tpw >>= 1;
+  // channel chunks per workgroup: all of them (x tile loaded once) unless the launch would be too small
+  int cpw = nchunks;
+  while (cpw > 1 && (long)(ntiles / tpw) * a.B * (nchunks / cpw) < 1024 && cpw % 2 == 0) cpw >>= 1;
+  static const std::string name = std::string("expand_dw_kernel<") + TypeName<T>::value + ", " + std::to_string(KS) + ", " +
+                                  (DBUF ? "1" : "0") + ">";
+  note_kernel(name.c_str());
+  hipLaunchKernelGGL((expand_dw_kernel<T, KS, DBUF>), dim3(ntiles / tpw, nchunks / cpw, a.B), dim3(256), lds, s, a, tpw, cpw);
+  return hipGetLastError();
+}
+template <typename T>
+static hipError_t launch_dw_t(const IrbxArgs& a, hipStream_t s) {
+  const int Cin = a.c0 + a.c1;
+  // double-buffered h1 tile (one barrier per chunk) while two workgroups still fit a CU's 160 KB of LDS
+  if (g_irbx_dbuf) {
+    switch (Cin) {
+      case 32: return launch_dw_cfg<T, 2, true>(a, s);
+      case 64: return launch_dw_cfg<T, 4, false>(a, s);
+      case 96: return launch_dw_cfg<T, 6, false>(a, s);
+    }
+  } else {
+    switch (Cin) {
+      case 32: return launch_dw_cfg<T, 2, false>(a, s);
+      case 64: return launch_dw_cfg<T, 4, false>(a, s);
+      case 96: return launch_dw_cfg<T, 6, false>(a, s);
+    }
+  }
+  return hipErrorInvalidValue;
+}
+hipError_t launch_expand_dw(int dtype, const IrbxArgs& a, hipStream_t s) {
+  if (!irbx_supported(dtype, a.c0 + a.c1, a.c0, a.Chid, a.H, a.W) || (a.c1 && !a.x1) || !a.out) return hipErrorInvalidValue;
+  return dtype == 1 ? launch_dw_t<half_t>(a, s) : launch_dw_t<bf16_t>(a, s);
+}
+
+}  // namespace llie

@@ -109,6 +109,24 @@ struct DwxArgs {
 };
 bool dwx_supported(int dtype, int Cin, int Chid, int H, int W);
 hipError_t launch_dwx(int dtype, const DwxArgs& a, hipStream_t s);
+// Recompute form of the block's front half (irbx.hip, 2-byte T): expand_stats writes only h1's statistics slab
+// ([B][P / irbx_stats_rows(P)][2][Chid]), expand_dw produces h2 and the SE pool slab ([B][irbx_pool_tiles][Chid]).
+struct IrbxArgs {
+  const void* x0; const void* x1; int c0, c1;   // block input (virtual concat), Cin = c0 + c1 in {32, 64, 96, 128}
+  const float* as1; const float* ab1;            // [B][Cin]   GroupNorm-1 affine (ReLU6 follows)
+  const void* w1;                                // [Chid][Cin] T
+  const float* as2; const float* ab2;            // [B][Chid]  GroupNorm-2 + FiLM affine (ReLU6 follows)
+  const float* wd;                               // [9][Chid] fp32 depthwise weights, tap-major
+  void* out; float* pool;                        // expand_dw outputs
+  float* stats;                                  // expand_stats output
+  int B, H, W, Chid;
+};
+bool irbx_supported(int dtype, int Cin, int c0, int Chid, int H, int W);
+int irbx_pool_tiles(int H, int W);
+int irbx_stats_rows(int P);
+void irbx_tune(int dbuf, int tiles_per_wg);
+hipError_t launch_expand_stats(int dtype, const IrbxArgs& a, hipStream_t s);
+hipError_t launch_expand_dw(int dtype, const IrbxArgs& a, hipStream_t s);
 int dwconv_ntiles(int H, int W);  // pool slab entries per image: (H/8 row segments) x (W / strip width)
 int dw_pick_tyl(int B, int H, int W, int chunks);
 void dwconv_swap(int v);   // 1: channel chunk is the fastest grid index

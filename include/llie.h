@@ -220,13 +220,16 @@ enum llie_kernel_class {
   LLIE_K_GEMM = 1,  /* pw_gemm_kernel: 1x1 convs with fused prologue / epilogue */
   LLIE_K_DW = 2,    /* dwconv3x3_kernel */
   LLIE_K_CONV3 = 4, /* conv3x3_kernel (down / up sampling convs) */
-  LLIE_K_SE = 8     /* squeeze-excitation MLP launches */
+  LLIE_K_SE = 8,    /* squeeze-excitation MLP launches */
+  LLIE_K_OTHER = 16 /* everything else on the forward path (norm finalize, attention core, input / output convs, time MLPs) */
 };
 int llie_profile_begin(llie_ctx* ctx, int class_mask);
 int llie_profile_end(llie_ctx* ctx, int kernel_class, double* total_ms, int64_t* launches, int64_t* algorithmic_bytes);
 /* Same data aggregated per kernel NAME (template arguments included, the granularity of
  * `rocprofv3 --kernel-trace --stats`): writes lines "name\tms\tlaunches\talgorithmic_bytes\n" into buf. */
 int llie_profile_report(llie_ctx* ctx, char* buf, size_t cap);
+/* Every recorded launch in launch order: lines "class\tkernel\toperator tag\tms\talgorithmic_bytes\n". */
+int llie_profile_dump(llie_ctx* ctx, char* buf, size_t cap);
 
 /* llie_algorithmic_bytes returns the roofline numerator of SURVEY.md 8d for one
  * UNet forward of `batch` images at the handle's dtype (activation traffic + weights once). */
