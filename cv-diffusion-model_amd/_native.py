@@ -25,7 +25,7 @@ EXPORTS = [
     "llie_profile_begin", "llie_profile_end", "llie_enhance_workspace_bytes",
     "llie_preprocess_u8", "llie_postprocess_u8", "llie_profile_report", "llie_pw_gemm", "llie_pw_gemm_tile_rows", "llie_dwconv3x3", "llie_dwconv3x3_tiles", "llie_tune",
     "llie_grad_numel", "llie_param_grad_offset", "llie_train_workspace_bytes", "llie_unet_train_forward",
-    "llie_unet_backward", "llie_module_backward", "llie_load_all", "llie_profile_dump",
+    "llie_unet_backward", "llie_module_backward", "llie_load_all", "llie_profile_dump", "llie_copy_probe", "llie_refresh_params", "llie_path_bytes",
 ]
 K_GEMM, K_DW, K_CONV3, K_SE, K_OTHER = 1, 2, 4, 8, 16
 
@@ -81,6 +81,7 @@ def lib() -> C.CDLL:
     L.llie_load_param.argtypes = [vp, C.c_char_p, vp, i64, vp]
     L.llie_params_loaded.argtypes = [vp]
     L.llie_load_all.argtypes = [vp, C.POINTER(vp), ci, vp]
+    L.llie_refresh_params.argtypes = [vp, C.POINTER(vp), ci, vp]
     L.llie_workspace_bytes.argtypes = [vp, ci, ci, ci]
     L.llie_workspace_bytes.restype = i64
     L.llie_enhance_workspace_bytes.argtypes = [vp, ci, ci]
@@ -88,10 +89,13 @@ def lib() -> C.CDLL:
     L.llie_unet_forward.argtypes = [vp, vp, vp, vp, ci, vp, ci, vp, i64, vp]
     L.llie_module_forward.argtypes = [vp, vp, vp, vp, ci, ci, ci, vp, i64, vp]
     L.llie_lcm_step.argtypes = [vp, vp, vp, vp, vp, vp, i64, C.POINTER(StepCoef), vp]
-    L.llie_add_noise.argtypes = [vp, vp, vp, vp, vp, ci, i64, ci, vp]
+    L.llie_add_noise.argtypes = [vp, vp, vp, vp, ci, vp, ci, i64, ci, vp]
+    L.llie_copy_probe.argtypes = [vp, vp, i64, vp]
     L.llie_enhance.argtypes = [vp, vp, vp, vp, C.POINTER(StepCoef), ci, vp, vp, vp, ci, vp, i64, vp]
     L.llie_algorithmic_bytes.argtypes = [vp, ci]
     L.llie_algorithmic_bytes.restype = i64
+    L.llie_path_bytes.argtypes = [vp, ci]
+    L.llie_path_bytes.restype = i64
     L.llie_flops.argtypes = [vp, ci]
     L.llie_flops.restype = i64
     L.llie_preprocess_u8.argtypes = [vp, ci, ci, ci, vp, ci, vp]
@@ -185,6 +189,11 @@ class Handle:
         arr = (C.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
         check(self._L.llie_load_all(self.h, arr, len(tensors), stream), "load_state_dict")
 
+    def refresh(self, tensors, stream: int) -> None:
+        """Reload only if the parameters' content changed since the last load (decided on the device, asynchronous)."""
+        arr = (C.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+        check(self._L.llie_refresh_params(self.h, arr, len(tensors), stream), "refresh_params")
+
     def params_loaded(self) -> bool:
         return bool(self._L.llie_params_loaded(self.h))
 
@@ -214,6 +223,9 @@ class Handle:
 
     def algorithmic_bytes(self, batch: int) -> int:
         return int(self._L.llie_algorithmic_bytes(self.h, batch))
+
+    def path_bytes(self, batch: int) -> int:
+        return int(self._L.llie_path_bytes(self.h, batch))
 
     def flops(self, batch: int) -> int:
         return int(self._L.llie_flops(self.h, batch))

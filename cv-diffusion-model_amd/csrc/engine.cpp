@@ -195,6 +195,8 @@ struct llie_ctx {
   // batched reload (llie_load_all): device descriptor table + the host pointers it was built for
   LoadDesc* load_descs = nullptr;
   std::vector<const float*> load_srcs;
+  unsigned long long* hash_partial = nullptr;  // [n][32] partial content hashes (llie_refresh_params)
+  unsigned long long* hash_state = nullptr;    // [0] hash of the last load, [1] "changed" flag read by load_all_kernel
   Tape tape;           // last training forward (llie_unet_train_forward), read by llie_unet_backward
   Arena* train_arena = nullptr;  // arena state after that forward; the backward pass continues in it
   size_t init_wp = 0, fin_wp = 0;  // MFMA-packed init / final conv weights (2-byte compute dtypes)
@@ -1513,6 +1515,8 @@ void llie_destroy(llie_ctx* c) {
   if (c->blob) (void)hipFree(c->blob);
   delete c->train_arena;
   if (c->load_descs) (void)hipFree(c->load_descs);
+  if (c->hash_partial) (void)hipFree(c->hash_partial);
+  if (c->hash_state) (void)hipFree(c->hash_state);
   delete c;
 }
 
@@ -1570,55 +1574,67 @@ int llie_load_param(llie_ctx* c, const char* key, const float* src, int64_t nume
   return LLIE_OK;
 }
 
-// Reload every parameter from `srcs[i]` (device fp32, llie_param_info order) -- what an optimiser step needs.  All
-// plain / matrix / 3x3 / depthwise tensors go through one kernel driven by a descriptor table that is rebuilt only
-// when a source pointer changes; the input and output convolutions keep their own repack kernels.
-int llie_load_all(llie_ctx* c, const float* const* srcs, int n, llie_stream stream) {
+// Reload every parameter from `srcs[i]` (device fp32, llie_param_info order) -- what an optimiser step needs.  Everything
+// goes through one kernel driven by a descriptor table that is rebuilt only when a source pointer changes.
+// conditional != 0 (llie_refresh_params): the reload happens on the device only if the parameters' content hash differs
+// from the one of the last load -- no host round trip, ~3 small launches when nothing changed.
+static int load_all_impl(llie_ctx* c, const float* const* srcs, int n, llie_stream stream, int conditional) {
   if (!c || !srcs || n != (int)c->params.size()) return LLIE_ERR_ARG;
   if (!c->blob) { set_err("no HIP device"); return LLIE_ERR_NO_DEVICE; }
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  std::vector<int> batched;
-  for (int i = 0; i < n; ++i) {
+  for (int i = 0; i < n; ++i)
     if (!srcs[i]) return LLIE_ERR_ARG;
-    const PKind k = c->params[i].kind;
-    if (k == PK_F32 || k == PK_MAT || k == PK_CONV3 || k == PK_DW) batched.push_back(i);
-  }
   bool rebuild = !c->load_descs || (int)c->load_srcs.size() != n;
   for (int i = 0; !rebuild && i < n; ++i) rebuild = c->load_srcs[i] != srcs[i];
   if (rebuild) {
     std::vector<LoadDesc> d;
-    for (int i : batched) {
+    for (int i = 0; i < n; ++i) {
       const Param& p = c->params[i];
       LoadDesc e{};
       e.src = srcs[i]; e.numel = p.numel; e.dst = (long long)p.off; e.dst_t = p.has_t ? (long long)p.t_off : -1;
       e.as_t = p.as_t ? 1 : 0; e.rows = p.rows; e.cols = p.cols; e.ld = p.ld; e.col0 = p.col0; e.O = p.O; e.I = p.I;
       e.Op = p.Op > 0 ? p.Op : p.O; e.Ip = p.Ip > 0 ? p.Ip : p.I;
       if (c->padded && p.kind != PK_DW) e.dst_t = -1;  // no backward pass for the padded variants (see llie_load_param)
-      e.kind = p.kind == PK_F32 ? 0 : (p.kind == PK_MAT ? 1 : (p.kind == PK_CONV3 ? 2 : 3));
+      switch (p.kind) {
+        case PK_F32: e.kind = 0; break;
+        case PK_MAT: e.kind = 1; break;
+        case PK_CONV3: e.kind = 2; break;
+        case PK_DW: e.kind = 3; break;
+        case PK_INIT: e.kind = 4; e.dst_t = c->dt != LLIE_F32 ? (long long)c->init_wp : -1; break;
+        case PK_FINAL: e.kind = 5; e.dst_t = c->dt != LLIE_F32 ? (long long)c->fin_wp : -1; break;
+      }
       d.push_back(e);
     }
     hipError_t e = hipSuccess;
     if (!c->load_descs) e = hipMalloc(reinterpret_cast<void**>(&c->load_descs), sizeof(LoadDesc) * c->params.size());
+    if (e == hipSuccess && !c->hash_partial) e = hipMalloc(reinterpret_cast<void**>(&c->hash_partial), sizeof(unsigned long long) * 32 * c->params.size());
+    if (e == hipSuccess && !c->hash_state) {
+      e = hipMalloc(reinterpret_cast<void**>(&c->hash_state), 2 * sizeof(unsigned long long));
+      if (e == hipSuccess) e = hipMemsetAsync(c->hash_state, 0, 2 * sizeof(unsigned long long), s);
+    }
     // pageable host memory: the copy is staged before the call returns, so the vector may go out of scope
     if (e == hipSuccess) e = hipMemcpyAsync(c->load_descs, d.data(), sizeof(LoadDesc) * d.size(), hipMemcpyHostToDevice, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     if (e != hipSuccess) { set_err("llie_load_all: %s", hipGetErrorString(e)); return (int)e; }
     c->load_srcs.assign(srcs, srcs + n);
-  }
-  if (!batched.empty()) {
-    hipError_t e = launch_load_all(c->dt, c->load_descs, (int)batched.size(), c->blob, s);
-    if (e != hipSuccess) { set_err("llie_load_all: %s", hipGetErrorString(e)); return (int)e; }
-    for (int i : batched) c->params[i].loaded = true;
-  }
-  for (int i = 0; i < n; ++i) {
-    const PKind k = c->params[i].kind;
-    if (k == PK_INIT || k == PK_FINAL) {
-      const int rc = llie_load_param(c, c->params[i].key.c_str(), srcs[i], c->params[i].numel, stream);
-      if (rc) return rc;
+    // the input / output convolutions' zero padding is written by their own repack kernels, once per source set
+    for (int i = 0; i < n; ++i) {
+      const PKind k = c->params[i].kind;
+      if (k == PK_INIT || k == PK_FINAL) {
+        const int rc = llie_load_param(c, c->params[i].key.c_str(), srcs[i], c->params[i].numel, stream);
+        if (rc) return rc;
+      }
     }
+    conditional = 0;
   }
+  hipError_t e = launch_params_hash(c->load_descs, n, c->hash_partial, c->hash_state, conditional ? 0 : 1, s);
+  if (e == hipSuccess) e = launch_load_all(c->dt, c->load_descs, n, c->blob, s, c->hash_state);
+  if (e != hipSuccess) { set_err("llie_load_all: %s", hipGetErrorString(e)); return (int)e; }
+  for (int i = 0; i < n; ++i) c->params[i].loaded = true;
   return LLIE_OK;
 }
+int llie_load_all(llie_ctx* c, const float* const* srcs, int n, llie_stream stream) { return load_all_impl(c, srcs, n, stream, 0); }
+int llie_refresh_params(llie_ctx* c, const float* const* srcs, int n, llie_stream stream) { return load_all_impl(c, srcs, n, stream, 1); }
 
 int llie_params_loaded(const llie_ctx* c) {
   if (!c) return 0;
@@ -1816,10 +1832,10 @@ int llie_lcm_step(const float* mo, const float* sample, const float* noise, floa
   return LLIE_OK;
 }
 
-int llie_add_noise(const float* x0, const float* noise, const int64_t* t, const float* acp, float* out, int batch,
+int llie_add_noise(const float* x0, const float* noise, const int64_t* t, const float* acp, int table_len, float* out, int batch,
                    int64_t per, int velocity, llie_stream stream) {
-  if (!x0 || !noise || !t || !acp || !out || batch <= 0 || per <= 0) return LLIE_ERR_ARG;
-  hipError_t e = launch_add_noise(x0, noise, t, acp, out, batch, per, velocity, reinterpret_cast<hipStream_t>(stream));
+  if (!x0 || !noise || !t || !acp || !out || batch <= 0 || per <= 0 || table_len <= 0) return LLIE_ERR_ARG;
+  hipError_t e = launch_add_noise(x0, noise, t, acp, out, batch, per, velocity, table_len, reinterpret_cast<hipStream_t>(stream));
   if (e != hipSuccess) { set_err("add_noise: %s", hipGetErrorString(e)); return (int)e; }
   return LLIE_OK;
 }
@@ -2014,6 +2030,14 @@ int llie_postprocess_u8(const float* x, int batch, int S, uint8_t* img, int H0, 
   return LLIE_OK;
 }
 
+int llie_copy_probe(const void* src, void* dst, int64_t bytes, llie_stream stream) {
+  if (!src || !dst || bytes <= 0) return LLIE_ERR_ARG;
+  hipError_t e = launch_copy_probe(src, dst, bytes, reinterpret_cast<hipStream_t>(stream));
+  if (e == hipErrorInvalidValue) return LLIE_ERR_ARG;
+  if (e != hipSuccess) { set_err("copy_probe: %s", hipGetErrorString(e)); return (int)e; }
+  return LLIE_OK;
+}
+
 int llie_dwconv3x3_tiles(int H, int W) { return dwconv_ntiles(H, W); }
 int llie_pw_gemm_tile_rows(int P) { return pw_gemm_tile_rows(P); }
 
@@ -2107,11 +2131,21 @@ int llie_profile_dump(llie_ctx* c, char* buf, size_t cap) {
 
 // SURVEY.md 8d byte model: IRB (2Cin + 4Chid + Cout)P, attention 6CP, dense 3x3 Cin*Pin + Cout*Pout,
 // final C0*P + 3P, LCM step 12P fp32; activations at the compute dtype; weights once.
-static void count_blocks(const llie_ctx* c, const std::vector<Block>& bl, int64_t P, int64_t& elems, int64_t& flops) {
+// engine != 0: what the engine's own kernel selection has to move -- blocks that run in the recompute form (irbx.hip)
+// read x three times and never store h1: (3Cin + 2Chid + Cout) P (SURVEY.md 8d "recompute variant").  x0c = channels of
+// the first input segment of the first block (virtual concat), 0 = none.
+static void count_blocks(const llie_ctx* c, const std::vector<Block>& bl, int64_t P, int64_t& elems, int64_t& flops, int engine = 0,
+                         int x0c = 0) {
+  bool first = true;
   for (const Block& b : bl) {
     if (b.kind == 0) {
       const IrbW& w = c->irbs[b.idx];
-      elems += (2LL * w.cin + 4LL * w.hid + w.cout) * P;
+      const int S = (int)std::lround(std::sqrt((double)P));
+      const bool fx = engine && g_use_irbx && w.hid == w.hid_r && w.cin == w.cin_r &&
+                      irbx_supported(c->dt, w.cin, (first && x0c) ? x0c : w.cin, w.hid, S, S);
+      first = false;
+      if (fx) elems += (3LL * w.cin + 2LL * w.hid + w.cout) * P;
+      else elems += (2LL * w.cin + 4LL * w.hid + w.cout) * P;
       flops += 2LL * P * ((int64_t)w.cin * w.hid + 9LL * w.hid + (int64_t)w.hid * w.cout + (w.skip ? (int64_t)w.cin * w.cout : 0));
     } else {
       const AttnW& w = c->attns[b.idx];
@@ -2120,7 +2154,7 @@ static void count_blocks(const llie_ctx* c, const std::vector<Block>& bl, int64_
     }
   }
 }
-static void model_counts(const llie_ctx* c, int64_t& elems, int64_t& flops) {
+static void model_counts(const llie_ctx* c, int64_t& elems, int64_t& flops, int engine = 0) {
   elems = flops = 0;
   if (c->cfg.kind != LLIE_UNET) return;
   const int S = c->cfg.image_size;
@@ -2129,14 +2163,14 @@ static void model_counts(const llie_ctx* c, int64_t& elems, int64_t& flops) {
   elems += (int64_t)c->cfg.in_channels * P + ch[0] * P;
   flops += 2LL * P * 9 * c->cfg.in_channels * ch[0];
   for (int l = 0; l < 4; ++l) {
-    count_blocks(c, c->enc[l], P, elems, flops);
+    count_blocks(c, c->enc[l], P, elems, flops, engine);
     if (l < 3) {
       elems += ch[l] * P + ch[l] * (P / 4);
       flops += 2LL * (P / 4) * 9 * ch[l] * ch[l];
       P /= 4;
     }
   }
-  count_blocks(c, c->mid, P, elems, flops);
+  count_blocks(c, c->mid, P, elems, flops, engine);
   for (int l = 0; l < 4; ++l) {
     if (l > 0) {
       const int cc = ch[4 - l];
@@ -2144,7 +2178,7 @@ static void model_counts(const llie_ctx* c, int64_t& elems, int64_t& flops) {
       flops += 2LL * (P * 4) * 9 * cc * cc;
       P *= 4;
     }
-    count_blocks(c, c->dec[l], P, elems, flops);
+    count_blocks(c, c->dec[l], P, elems, flops, engine, l == 0 ? ch[3] : ch[4 - l]);
   }
   elems += (int64_t)ch[0] * P + 3 * P;
   flops += 2LL * P * 9 * ch[0] * c->cfg.out_channels;
@@ -2154,6 +2188,14 @@ int64_t llie_algorithmic_bytes(llie_ctx* c, int batch) {
   if (!c) return LLIE_ERR_ARG;
   int64_t elems, flops;
   model_counts(c, elems, flops);
+  int64_t wbytes = 0;
+  for (const Param& p : c->params) wbytes += p.numel * (p.kind == PK_F32 || !p.as_t ? 4 : (int64_t)elem_size(c->dt));
+  return elems * batch * (int64_t)elem_size(c->dt) + wbytes;
+}
+int64_t llie_path_bytes(llie_ctx* c, int batch) {
+  if (!c) return LLIE_ERR_ARG;
+  int64_t elems, flops;
+  model_counts(c, elems, flops, 1);
   int64_t wbytes = 0;
   for (const Param& p : c->params) wbytes += p.numel * (p.kind == PK_F32 || !p.as_t ? 4 : (int64_t)elem_size(c->dt));
   return elems * batch * (int64_t)elem_size(c->dt) + wbytes;

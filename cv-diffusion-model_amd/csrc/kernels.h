@@ -251,12 +251,17 @@ hipError_t launch_repack_init_mfma(int dtype, const float* src, void* dst, int O
 // small repack launches would cost more than the repack itself).  Offsets are bytes into the weight blob; -1 = none.
 struct LoadDesc {
   const float* src;
-  int kind;            // 0 fp32 copy, 1 matrix (cvt_rows [+ transposed copy]), 2 OIHW 3x3 ([tap][O][I] [+ [8-tap][I][O]]), 3 depthwise ([tap][C] + flipped)
+  int kind;            // 0 fp32 copy, 1 matrix (cvt_rows [+ transposed copy]), 2 OIHW 3x3 ([tap][O][I] [+ [8-tap][I][O]]), 3 depthwise ([tap][C] + flipped),
+                       // 4 input conv (fp32 [I*9][Op] + MFMA pack at dst_t), 5 output conv (fp32 [9][Ip][4] + MFMA pack at dst_t)
   int as_t;            // matrix: destination in the compute dtype (1) or fp32 (0)
   int rows, cols, ld, col0, O, I, Op, Ip;  // Op / Ip: padded destination dims of the 3x3 / depthwise layouts
   long long numel, dst, dst_t;
 };
-hipError_t launch_load_all(int dtype, const LoadDesc* descs_dev, int n, char* blob, hipStream_t s);
+// state (optional, device): [0] = content hash of the last load, [1] = 1 when the parameters changed (set by launch_params_hash);
+// with a state the kernel is a no-op when [1] == 0
+hipError_t launch_load_all(int dtype, const LoadDesc* descs_dev, int n, char* blob, hipStream_t s, const unsigned long long* state = nullptr);
+hipError_t launch_params_hash(const LoadDesc* descs_dev, int n, unsigned long long* partial, unsigned long long* state, int force,
+                              hipStream_t s);
 
 // uint8 HWC RGB <-> normalised fp32 NCHW with bilinear resize (scripts/inference.py:99-134), bit-exact with hostio.py.
 hipError_t launch_preprocess_u8(const uint8_t* img, int B, int H0, int W0, float* out, int S, hipStream_t s);
@@ -266,7 +271,8 @@ hipError_t launch_postprocess_u8(const float* x, int B, int S, uint8_t* img, int
 hipError_t launch_lcm_step(const float* eps, const float* x, const float* noise, float* prev, float* x0,
                            float* clamped, int64_t n, StepCoef c, hipStream_t s);
 hipError_t launch_add_noise(const float* x0, const float* noise, const int64_t* t, const float* acp, float* out,
-                            int B, int64_t per, int velocity, hipStream_t s);
+                            int B, int64_t per, int velocity, int table_len, hipStream_t s);
+hipError_t launch_copy_probe(const void* src, void* dst, int64_t bytes, hipStream_t s);
 
 
 // =============================================================================================

@@ -631,8 +631,49 @@ hipError_t launch_repack_dw_flip(const float* src, float* dst, int C, hipStream_
   return hipGetLastError();
 }
 
+// Content hash of every parameter (fp32 bits, position-weighted, summed mod 2^64: the order of the partial sums does
+// not matter), so that writes PyTorch's version counters cannot see (`p.data.copy_()`, the reference's EMA
+// apply_shadow / restore, trainer.py:104-117) are noticed without a host round trip: hash_finalize compares with
+// the hash of the last load and raises state[1]; load_all_kernel does nothing when state[1] == 0.
+__global__ void __launch_bounds__(256) params_hash_kernel(const LoadDesc* descs, unsigned long long* partial) {
+  const LoadDesc d = descs[blockIdx.y];
+  const uint32_t* src = reinterpret_cast<const uint32_t*>(d.src);
+  unsigned long long acc = 0;
+  const unsigned long long wy = 0x9E3779B97F4A7C15ull * (unsigned long long)(blockIdx.y + 1);
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < d.numel; i += (long long)gridDim.x * 256)
+    acc += (unsigned long long)src[i] * ((wy + 0xD1B54A32D192ED03ull * (unsigned long long)(i + 1)) | 1ull);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+  __shared__ unsigned long long red[4];
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+__global__ void __launch_bounds__(256) hash_finalize_kernel(const unsigned long long* partial, int count, unsigned long long* state,
+                                                            int force) {
+  unsigned long long acc = 0;
+  for (int i = threadIdx.x; i < count; i += 256) acc += partial[i];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+  __shared__ unsigned long long red[4];
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned long long h = red[0] + red[1] + red[2] + red[3];
+    state[1] = (force || h != state[0]) ? 1ull : 0ull;
+    state[0] = h;
+  }
+}
+hipError_t launch_params_hash(const LoadDesc* descs_dev, int n, unsigned long long* partial, unsigned long long* state, int force,
+                              hipStream_t s) {
+  hipLaunchKernelGGL(params_hash_kernel, dim3(32, n), dim3(256), 0, s, descs_dev, partial);
+  hipLaunchKernelGGL(hash_finalize_kernel, dim3(1), dim3(256), 0, s, partial, 32 * n, state, force);
+  return hipGetLastError();
+}
+
 template <typename T>
-__global__ void __launch_bounds__(256) load_all_kernel(const LoadDesc* descs, char* blob) {
+__global__ void __launch_bounds__(256) load_all_kernel(const LoadDesc* descs, char* blob, const unsigned long long* state) {
+  if (state && state[1] == 0) return;  // parameters unchanged since the last load
   const LoadDesc d = descs[blockIdx.y];
   const float* src = d.src;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < d.numel; i += (long long)gridDim.x * 256) {
@@ -650,19 +691,34 @@ __global__ void __launch_bounds__(256) load_all_kernel(const LoadDesc* descs, ch
       const int ci = (int)((i / 9) % d.I), co = (int)(i / (9 * (long long)d.I));
       reinterpret_cast<T*>(blob + d.dst)[((size_t)tap * d.Op + co) * d.Ip + ci] = (T)v;
       if (d.dst_t >= 0) reinterpret_cast<T*>(blob + d.dst_t)[((size_t)(8 - tap) * d.Ip + ci) * d.Op + co] = (T)v;
-    } else {
+    } else if (d.kind == 3) {
       const int tap = (int)(i % 9), c = (int)(i / 9);
       reinterpret_cast<float*>(blob + d.dst)[(size_t)tap * d.Op + c] = v;
       if (d.dst_t >= 0) reinterpret_cast<float*>(blob + d.dst_t)[(size_t)(8 - tap) * d.Op + c] = v;
+    } else if (d.kind == 4) {  // init conv OIHW: fp32 [I*9][Op], and (2-byte T) the MFMA pack [tap][Op][8]; padding entries
+                               // keep the zeros the first full load wrote (launch_repack_init*)
+      const int k = (int)(i % (d.I * 9)), o = (int)(i / (d.I * 9));
+      reinterpret_cast<float*>(blob + d.dst)[(size_t)k * d.Op + o] = v;
+      if (d.dst_t >= 0) {
+        const int tap = k % 9, ci = k / 9;
+        reinterpret_cast<T*>(blob + d.dst_t)[((size_t)tap * d.Op + o) * 8 + ci] = (T)v;
+      }
+    } else {  // kind 5: output conv OIHW (O <= 4): fp32 [9][Ip][4], and the MFMA pack [Ip/32][18][2][4][8]
+      const int tap = (int)(i % 9), ci = (int)((i / 9) % d.I), o = (int)(i / (9 * (long long)d.I));
+      reinterpret_cast<float*>(blob + d.dst)[((size_t)tap * d.Ip + ci) * 4 + o] = v;
+      if (d.dst_t >= 0) {
+        const int chunk = ci >> 5, r = ci & 31, ks = tap * 2 + (r >> 4), hh = (r >> 3) & 1, j = r & 7;
+        reinterpret_cast<T*>(blob + d.dst_t)[((((size_t)chunk * 18 + ks) * 2 + hh) * 4 + o) * 8 + j] = (T)v;
+      }
     }
   }
 }
-hipError_t launch_load_all(int dtype, const LoadDesc* descs_dev, int n, char* blob, hipStream_t s) {
+hipError_t launch_load_all(int dtype, const LoadDesc* descs_dev, int n, char* blob, hipStream_t s, const unsigned long long* state) {
   dim3 grid(32, n);
   switch (dtype) {
-    case 0: hipLaunchKernelGGL(load_all_kernel<float>, grid, dim3(256), 0, s, descs_dev, blob); break;
-    case 1: hipLaunchKernelGGL(load_all_kernel<half_t>, grid, dim3(256), 0, s, descs_dev, blob); break;
-    case 2: hipLaunchKernelGGL(load_all_kernel<bf16_t>, grid, dim3(256), 0, s, descs_dev, blob); break;
+    case 0: hipLaunchKernelGGL(load_all_kernel<float>, grid, dim3(256), 0, s, descs_dev, blob, state); break;
+    case 1: hipLaunchKernelGGL(load_all_kernel<half_t>, grid, dim3(256), 0, s, descs_dev, blob, state); break;
+    case 2: hipLaunchKernelGGL(load_all_kernel<bf16_t>, grid, dim3(256), 0, s, descs_dev, blob, state); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();
@@ -848,21 +904,34 @@ hipError_t launch_lcm_step(const float* eps, const float* x, const float* noise,
   return hipGetLastError();
 }
 // add_noise / get_velocity (lcm_scheduler.py:255-305)
+// A timestep outside [0, table_len) (an IndexError in the reference) never indexes the table: the sample comes out NaN.
 __global__ void add_noise_kernel(const float* x0, const float* noise, const int64_t* t, const float* acp, float* out,
-                                 int64_t per, int velocity) {
+                                 int64_t per, int velocity, int table_len) {
 #pragma clang fp contract(off)
   const int b = blockIdx.y;
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= per) return;
-  const float a = acp[t[b]];
+  const int64_t tb = t[b];
+  const float a = (tb >= 0 && tb < table_len) ? acp[tb] : __builtin_nanf("");
   const float sa = sqrtf(a), sb = sqrtf(1.f - a);
   const size_t o = (size_t)b * per + i;
   out[o] = velocity ? sa * noise[o] - sb * x0[o] : sa * x0[o] + sb * noise[o];
 }
 hipError_t launch_add_noise(const float* x0, const float* noise, const int64_t* t, const float* acp, float* out, int B,
-                            int64_t per, int velocity, hipStream_t s) {
+                            int64_t per, int velocity, int table_len, hipStream_t s) {
   dim3 grid((unsigned)((per + 255) / 256), B);
-  hipLaunchKernelGGL(add_noise_kernel, grid, dim3(256), 0, s, x0, noise, t, acp, out, per, velocity);
+  hipLaunchKernelGGL(add_noise_kernel, grid, dim3(256), 0, s, x0, noise, t, acp, out, per, velocity, table_len);
+  return hipGetLastError();
+}
+
+// HBM copy-bandwidth probe (bench.py `peak_measured`): 16 bytes per lane, grid-stride.
+__global__ void __launch_bounds__(256) copy_probe_kernel(const u32x4* __restrict__ src, u32x4* __restrict__ dst, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+hipError_t launch_copy_probe(const void* src, void* dst, int64_t bytes, hipStream_t s) {
+  if (bytes % 16) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(copy_probe_kernel, dim3(256 * 16), dim3(256), 0, s, reinterpret_cast<const u32x4*>(src),
+                     reinterpret_cast<u32x4*>(dst), bytes / 16);
   return hipGetLastError();
 }
 

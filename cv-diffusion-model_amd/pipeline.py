@@ -50,6 +50,12 @@ class LowLightDiffusion(nn.Module):
             num_train_timesteps=1000, beta_schedule="scaled_linear", prediction_type="epsilon",
             num_inference_steps=num_inference_steps, rescale_betas_zero_snr=True)
         self.compute_dtype = compute_dtype
+        object.__setattr__(self, "_t_cache", {})  # (timesteps, batch, device) -> device int64 [steps*B]
+
+    def __getstate__(self):  # copy.deepcopy / pickling: device caches are rebuilt lazily
+        st = dict(self.__dict__)
+        st["_t_cache"] = {}
+        return st
 
     @property
     def compute_dtype(self) -> Optional[str]:
@@ -112,9 +118,11 @@ class LowLightDiffusion(nn.Module):
         steps = len(ts)
 
         if noise is None:
-            draws = [torch.randn(b, 3, s, s, device=device, generator=generator)]
-            draws += [torch.randn(b, 3, s, s, device=device) for _ in range(steps - 1)]
-            noise_t = torch.stack(draws)
+            # drawn straight into the [steps,B,3,S,S] buffer the engine reads (same generator streams as torch.randn)
+            noise_t = torch.empty(steps, b, 3, s, s, dtype=torch.float32, device=device)
+            noise_t[0].normal_(generator=generator)
+            for i in range(1, steps):
+                noise_t[i].normal_()
         else:
             noise_t = noise if isinstance(noise, torch.Tensor) else torch.stack([n.to(device) for n in noise])
             noise_t = noise_t.to(device=device, dtype=torch.float32)
@@ -123,7 +131,12 @@ class LowLightDiffusion(nn.Module):
         noise_t = noise_t.contiguous()
 
         coefs = (N.StepCoef * steps)(*[self.scheduler.step_coefficients(t) for t in ts])
-        t_dev = torch.tensor(ts, dtype=torch.long).repeat_interleave(b).to(device)  # [steps*B]
+        tkey = (tuple(ts), b, device.type, device.index)
+        t_dev = self._t_cache.get(tkey)  # [steps*B] device timesteps: one H2D copy per (schedule, batch), not per call
+        if t_dev is None:
+            if len(self._t_cache) > 64:
+                self._t_cache.clear()
+            t_dev = self._t_cache[tkey] = torch.tensor(ts, dtype=torch.long).repeat_interleave(b).to(device)
         low = low_light.detach().float().contiguous()
         enhanced = torch.empty(b, 3, s, s, dtype=torch.float32, device=device)
         inter = torch.empty(steps, b, 3, s, s, dtype=torch.float32, device=device) if return_intermediate else None
@@ -144,9 +157,16 @@ class LowLightDiffusion(nn.Module):
         return enhanced
 
     # ------------------------------------------------------------------ loss (:250-277)
-    def compute_loss(self, low_light: torch.Tensor, normal_light: torch.Tensor, loss_type: str = "mse") -> torch.Tensor:
+    def compute_loss(self, low_light: torch.Tensor, normal_light: torch.Tensor, loss_type: str = "mse", *,
+                     use_velocity_target: bool = False) -> torch.Tensor:
+        """Regresses the denoiser output against the drawn noise, as the reference does whatever the scheduler's
+        prediction type (low_light_diffusion.py:262-275).  `use_velocity_target=True` (extension, needs a
+        `prediction_type="v_prediction"` scheduler) regresses against `scheduler.get_velocity` instead -- the v-pred MSE of
+        BASELINE config 5, which the reference defines (lcm_scheduler.py:282-305) but never wires into its loss."""
         out = self.forward(low_light, normal_light)
-        pred, noise = out["noise_pred"], out.get("target", out["noise"])  # epsilon target, or velocity for v-prediction
+        if use_velocity_target and "target" not in out:
+            raise ValueError("use_velocity_target needs a scheduler with prediction_type='v_prediction'")
+        pred, noise = out["noise_pred"], (out["target"] if use_velocity_target else out["noise"])
         if loss_type == "mse":
             return F.mse_loss(pred, noise)
         if loss_type == "huber":

@@ -138,11 +138,18 @@ class LCMScheduler:
     def _noise_op(self, a: torch.Tensor, b: torch.Tensor, timesteps: torch.Tensor, velocity: int) -> torch.Tensor:
         _require_cuda(a, "LCMScheduler.add_noise/get_velocity")
         a_c, b_c = a.detach().float().contiguous(), b.detach().float().contiguous()
+        n_table = int(self.alphas_cumprod.numel())
+        if timesteps.device.type == "cpu" and timesteps.numel() and (int(timesteps.min()) < -n_table or int(timesteps.max()) >= n_table):
+            # the reference indexes a tensor with the timesteps (lcm_scheduler.py:268) and raises; device-resident
+            # timesteps cannot be checked without a sync: the kernel turns an out-of-range one into NaN output instead
+            raise IndexError(f"timestep out of range for a table of {n_table} entries")
         t = timesteps.to(device=a.device, dtype=torch.long).contiguous()
+        if timesteps.device.type == "cpu" and timesteps.numel() and int(timesteps.min()) < 0:
+            t = torch.where(t < 0, t + n_table, t)  # negative indices wrap like tensor indexing does
         out = torch.empty_like(a_c)
         batch = a_c.shape[0]
         with torch.cuda.device(a.device):
-            N.check(N.lib().llie_add_noise(a_c.data_ptr(), b_c.data_ptr(), t.data_ptr(), self._acp_on(a.device).data_ptr(),
+            N.check(N.lib().llie_add_noise(a_c.data_ptr(), b_c.data_ptr(), t.data_ptr(), self._acp_on(a.device).data_ptr(), n_table,
                                            out.data_ptr(), batch, a_c.numel() // batch, velocity,
                                            torch.cuda.current_stream(a.device).cuda_stream), "add_noise")
         return out
@@ -237,10 +244,13 @@ class LCMDenoisingLoop:
         key = (a.device.type, a.device.index)
         if key not in self._acp_dev:
             self._acp_dev[key] = torch.from_numpy(self.alphas_cumprod).to(device=a.device, dtype=torch.float32).contiguous()
-        t = torch.full((a.shape[0],), int(timestep), dtype=torch.long, device=a.device)
+        n_table = len(self.alphas_cumprod)
+        if not -n_table <= int(timestep) < n_table:
+            raise IndexError(f"timestep {int(timestep)} out of range for a table of {n_table} entries")  # numpy indexing in the reference
+        t = torch.full((a.shape[0],), int(timestep) % n_table, dtype=torch.long, device=a.device)
         out = torch.empty_like(a)
         with torch.cuda.device(a.device):
-            N.check(N.lib().llie_add_noise(a.data_ptr(), b.data_ptr(), t.data_ptr(), self._acp_dev[key].data_ptr(),
+            N.check(N.lib().llie_add_noise(a.data_ptr(), b.data_ptr(), t.data_ptr(), self._acp_dev[key].data_ptr(), n_table,
                                            out.data_ptr(), a.shape[0], a[0].numel(), 0,
                                            torch.cuda.current_stream(a.device).cuda_stream), "LCMDenoisingLoop.add_noise")
         return out

@@ -157,8 +157,9 @@ class _NativeModule(nn.Module):
         super().__init__()
         self._cfg_proto = cfg
         self.compute_dtype: Optional[str] = None  # None -> fp32, or autocast's dtype when active
-        object.__setattr__(self, "_handles", {})   # (device index, dtype code) -> (Handle, version signature)
+        object.__setattr__(self, "_handles", {})   # (device index, dtype code) -> (Handle, version signature, source tensors)
         object.__setattr__(self, "_workspaces", {})
+        object.__setattr__(self, "_plist_cache", None)
         desc = N.Handle(self._make_cfg(N.LLIE_F32))  # describes the state_dict; validates the topology
         self._param_list = desc.params()
         desc.close()
@@ -177,8 +178,43 @@ class _NativeModule(nn.Module):
         c.compute_dtype = dtype_code
         return c
 
+    # Ordered Parameter objects (llie_param_info order), cached: walking named_parameters() costs ~1 ms per call on a
+    # 321-tensor model.  nn.Module replaces Parameter objects only through _apply (with the overwrite-on-conversion
+    # future flag), register_parameter or attribute assignment -- the first two invalidate the cache below, the third is
+    # not something the reference's callers do to this model.
+    def _plist(self):
+        pl = self.__dict__.get("_plist_cache")
+        if pl is None:
+            sd = dict(self.named_parameters())
+            pl = [sd[k] for k, _ in self._param_list]
+            object.__setattr__(self, "_plist_cache", pl)
+        return pl
+
+    def _apply(self, fn, *args, **kwargs):
+        object.__setattr__(self, "_plist_cache", None)
+        return super()._apply(fn, *args, **kwargs)
+
     def _signature(self):
-        return tuple((p._version, p.data_ptr()) for p in self.parameters())
+        return tuple((p._version, p.data_ptr()) for p in self._plist())
+
+    # copy.deepcopy(model) is how the reference builds its EMA / target networks (low_light_diffusion.py:312,
+    # lcm_scheduler.py:353): the copy gets its own engine context lazily, ctypes handles are not copied.
+    def __getstate__(self):
+        st = dict(self.__dict__)
+        st["_handles"], st["_workspaces"], st["_plist_cache"] = {}, {}, None
+        return st
+
+    def __setstate__(self, state):
+        super().__setstate__(state)
+        object.__setattr__(self, "_handles", {})
+        object.__setattr__(self, "_workspaces", {})
+        object.__setattr__(self, "_plist_cache", None)
+
+    def mark_weights_dirty(self) -> None:
+        """Force a full repack at the next call (never needed for correctness: in-place writes that PyTorch's version
+        counters miss are caught by the engine's on-device content hash, llie_refresh_params)."""
+        for key, (h, _sig, _ts) in list(self._handles.items()):
+            self._handles[key] = (h, None, None)
 
     def _device(self) -> torch.device:
         return next(self.parameters()).device
@@ -192,20 +228,24 @@ class _NativeModule(nn.Module):
         key = (dev.index if dev.index is not None else torch.cuda.current_device(), dtype_code)
         sig = self._signature()
         entry = self._handles.get(key)
-        if entry is not None and entry[1] == sig:
-            return entry[0]
         with torch.cuda.device(dev):
-            h = entry[0] if entry is not None else N.Handle(self._make_cfg(dtype_code))
             stream = torch.cuda.current_stream(dev).cuda_stream
-            sd = dict(self.named_parameters())
+            if entry is not None and entry[1] == sig:
+                # same tensors, same version counters: `p.data.copy_()` style writes (the reference's EMA, trainer.py:104-117)
+                # are still possible -- the engine compares a content hash on the device and reloads only if it differs
+                entry[0].refresh(entry[2], stream)
+                return entry[0]
+            h = entry[0] if entry is not None else N.Handle(self._make_cfg(dtype_code))
             ts = []
-            for k, _ in self._param_list:
-                t = sd[k].detach()
+            for t in self._plist():
+                t = t.detach()
                 if t.dtype != torch.float32 or not t.is_contiguous():
                     t = t.float().contiguous()
                 ts.append(t)
-            h.load_all(ts, stream)  # one repack launch for (almost) everything: an optimiser step touches every tensor
-        self._handles[key] = (h, sig)
+            h.load_all(ts, stream)  # one repack launch for everything: an optimiser step touches every tensor
+            # a non-fp32 / non-contiguous parameter is loaded from a temporary: no stable source for the hash, reload each time
+            stable = all(a.data_ptr() == b.data_ptr() for a, b in zip(ts, self._plist()))
+        self._handles[key] = (h, sig if stable else None, ts)
         return h
 
     def _workspace(self, h: N.Handle, nbytes: int, dev: torch.device) -> torch.Tensor:
@@ -228,8 +268,7 @@ class _NativeModule(nn.Module):
         return self._run_module_raw(x, temb, out_shape)
 
     def _ordered_params(self):
-        sd = dict(self.named_parameters())
-        return [(k, sd[k]) for k, _ in self._param_list]
+        return [(k, p) for (k, _), p in zip(self._param_list, self._plist())]
 
     def _run_module_backward(self, x: torch.Tensor, temb: Optional[torch.Tensor], dy: torch.Tensor):
         h = self._handle(resolve_compute_dtype(self.compute_dtype))

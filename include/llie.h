@@ -111,6 +111,11 @@ int llie_load_param(llie_ctx* ctx, const char* key, const float* src, int64_t nu
  * llie_param_info order (host array of n = llie_num_params pointers).  One kernel for all plain / 1x1 / 3x3 /
  * depthwise tensors; equivalent to n llie_load_param calls. */
 int llie_load_all(llie_ctx* ctx, const float* const* srcs, int n, llie_stream stream);
+/* Same arguments; reloads only if the parameters' CONTENT differs from the last load.  The comparison (a 64-bit
+ * position-weighted hash of the fp32 bits) and the decision both happen on the device, so the call stays asynchronous:
+ * it catches in-place writes that bypass PyTorch's version counters -- `param.data.copy_(...)`, which is how the
+ * reference's EMA swaps weights in and out (src/training/trainer.py:104-117, low_light_diffusion.py:317-323). */
+int llie_refresh_params(llie_ctx* ctx, const float* const* srcs, int n, llie_stream stream);
 int llie_params_loaded(const llie_ctx* ctx); /* 1 when every key has been loaded */
 
 /* Bytes of scratch the forward needs for a batch (UNET: spatial size = image_size; single
@@ -166,7 +171,9 @@ int llie_lcm_step(const float* model_output, const float* sample, const float* n
 /* LCMScheduler.add_noise / get_velocity (lcm_scheduler.py:255-305): per-sample timesteps (device
  * int64[B]) index a device fp32 alpha-bar table [num_train_timesteps]; tensors fp32 [B, per_sample]. */
 int llie_add_noise(const float* x0, const float* noise, const int64_t* timesteps, const float* alphas_cumprod,
-                   float* out, int batch, int64_t per_sample, int velocity, llie_stream stream);
+                   int table_len, float* out, int batch, int64_t per_sample, int velocity, llie_stream stream);
+/* A timestep outside [0, table_len) -- an IndexError in the reference -- is never used as an index: that sample's
+ * output is NaN (the call is asynchronous and cannot raise; the Python layer validates host-side timesteps). */
 
 /* Whole denoising loop of LowLightDiffusion.enhance (low_light_diffusion.py:204-240) on one stream:
  * `noise` is fp32 [steps,B,3,S,S] in the reference's draw order (initial latents first, then one draw
@@ -208,6 +215,9 @@ int llie_pw_gemm_tile_rows(int P);
 int llie_dwconv3x3(int dtype, const void* in, void* out, const float* scale, const float* bias, const float* w9c,
                    float* pool, int B, int H, int W, int C, llie_stream stream);
 int llie_dwconv3x3_tiles(int H, int W);
+/* dst[0:bytes] = src[0:bytes] with 16-byte lane accesses: the on-box HBM copy-bandwidth probe behind bench.py's
+ * `peak_measured` ("a copy-kernel bandwidth probe"; 2 x bytes move per call). */
+int llie_copy_probe(const void* src, void* dst, int64_t bytes, llie_stream stream);
 int llie_tune(const char* knob, int value); /* tuning knobs for tools/gpu_tune.py: "gemm_bk" = 0 (auto) | 32 */
 
 /* Per-kernel-class timing with HIP events recorded on the launch stream (what bench.py's `roofline`
@@ -235,6 +245,9 @@ int llie_profile_dump(llie_ctx* ctx, char* buf, size_t cap);
  * UNet forward of `batch` images at the handle's dtype (activation traffic + weights once). */
 int64_t llie_algorithmic_bytes(llie_ctx* ctx, int batch);
 int64_t llie_flops(llie_ctx* ctx, int batch);
+/* Same model with the blocks the engine runs in the recompute form (irbx.hip: h1 is never stored) counted as
+ * (3Cin + 2Chid + Cout) P -- the bytes the engine's own kernel selection has to move. */
+int64_t llie_path_bytes(llie_ctx* ctx, int batch);
 
 #ifdef __cplusplus
 }

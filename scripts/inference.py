@@ -31,6 +31,9 @@ def parse_args(argv=None):
     p.add_argument("--num_steps", type=int, default=4)
     p.add_argument("--device", type=str, default="cuda" if torch.cuda.is_available() else "cpu")
     p.add_argument("--dtype", type=str, default="fp32", choices=["fp32", "fp16", "bf16"], help="engine precision (extension)")
+    p.add_argument("--noise_seed", type=int, default=None,
+                   help="(extension) draw the loop's noise on the CPU generator with this seed, in the reference's order, "
+                        "instead of on the device: makes a run reproducible against the CPU reference")
     return p.parse_args(argv)
 
 
@@ -53,7 +56,11 @@ def process_single_image(args, model, input_path: str, output_path: str) -> floa
         # uint8 goes up, uint8 comes back: resize + normalise / denormalise run on the device
         # (bit-exact twins of hostio.preprocess_array / postprocess_array, i.e. inference.py:99-134)
         x = hostio.preprocess_device(torch.from_numpy(rgb).to(args.device), args.image_size)
-        enhanced = model.enhance(x, num_inference_steps=args.num_steps)
+        noise = None
+        if args.noise_seed is not None:  # reference draw order: initial latents, then one draw per non-final step
+            g = torch.Generator().manual_seed(args.noise_seed)
+            noise = torch.stack([torch.randn(1, 3, args.image_size, args.image_size, generator=g) for _ in range(args.num_steps)])
+        enhanced = model.enhance(x, num_inference_steps=args.num_steps, noise=noise)
         out = hostio.postprocess_device(enhanced, original)[0].cpu().numpy()
     elapsed = time.perf_counter() - start
     hostio.save_image(output_path, out)

@@ -86,25 +86,60 @@ def test_device_pre_post_processing_bit_exact(shape, size):
     assert gotp.dtype == np.uint8 and np.array_equal(gotp, refp)
 
 
+@pytest.mark.parametrize("shape,size", [((37, 53), 64), ((200, 120), 64), ((64, 64), 64), ((96, 160), 128)])
+def test_host_io_vs_oracle(shape, size):
+    """Product host path (hostio.py, fp32 NumPy) against the oracle's restatement of scripts/inference.py:99-134
+    (oracle/hostio_ref.py, float64): normalise / denormalise / clip / truncate / layout exact; the bilinear resize
+    within one LSB (fp32 vs float64 at round-half-up ties), identical in > 99.9 % of the bytes."""
+    from oracle import hostio_ref
+    rng = np.random.default_rng(11)
+    img = rng.integers(0, 256, size=shape + (3,), dtype=np.uint8)
+    x, orig = M.preprocess_array(img, size)
+    xr, origr = hostio_ref.preprocess_ref(img, size)
+    assert orig == origr and x.shape == xr.shape and x.dtype == xr.dtype
+    d = np.abs(x - xr) * 127.5
+    assert d.max() <= 1.0 + 1e-4 and (d > 1e-4).mean() < 1e-2
+    y = (rng.random((1, 3, size, size), dtype=np.float32) * 2.6 - 1.3)
+    p, pr = M.postprocess_array(y, shape), hostio_ref.postprocess_ref(y, shape)
+    dp = np.abs(p.astype(np.int64) - pr.astype(np.int64))
+    assert p.shape == pr.shape and dp.max() <= 1 and (dp > 0).mean() < 5e-2  # near-.5 ties (rational scale factors) round apart in fp32 vs float64
+    if shape == (size, size):  # no resize involved: byte-exact both ways
+        assert np.array_equal(x, xr) and np.array_equal(p, pr)
+
+
 @pytest.mark.gpu
 def test_cli_end_to_end(tmp_path):
     from PIL import Image
+    from oracle import hostio_ref
     spec = oracle.make_spec("small", 64)
     sd = oracle.synth_state_dict(oracle.param_shapes(spec))
     ckpt = tmp_path / "ckpt.pt"
     torch.save({"epoch": 1, "model_state_dict": dict(sd)}, ckpt)
     rng = np.random.default_rng(2)
     src = tmp_path / "in"; src.mkdir()
+    imgs = []
     for i, (h, w) in enumerate([(48, 80), (100, 70)]):
-        Image.fromarray((rng.random((h, w, 3)) * 60).astype(np.uint8)).save(src / f"dark{i}.png")
+        imgs.append((rng.random((h, w, 3)) * 60).astype(np.uint8))
+        Image.fromarray(imgs[-1]).save(src / f"dark{i}.png")
     dst = tmp_path / "out"
     r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "inference.py"), "--input", str(src), "--output", str(dst),
-                        "--checkpoint", str(ckpt), "--variant", "small", "--image_size", "64", "--num_steps", "4"],
+                        "--checkpoint", str(ckpt), "--variant", "small", "--image_size", "64", "--num_steps", "4",
+                        "--noise_seed", "77"],
                        capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
     for i, (h, w) in enumerate([(48, 80), (100, 70)]):
         out = np.asarray(Image.open(dst / f"dark{i}.png"))
         assert out.shape == (h, w, 3) and out.dtype == np.uint8
+        # pixel values: the whole file -> file path against the CPU oracle (preprocess -> 4-step enhance -> postprocess,
+        # scripts/inference.py:99-145) on the same seeded CPU noise.  The fp32 engine is within 1e-3 of the oracle, so
+        # the bytes agree except where a value sits on a truncation / rounding boundary: at most one LSB, rarely.
+        x, orig = hostio_ref.preprocess_ref(imgs[i], 64)
+        g = torch.Generator().manual_seed(77)
+        noise = [torch.randn(1, 3, 64, 64, generator=g) for _ in range(4)]
+        ref = oracle.enhance_ref(sd, spec, torch.from_numpy(x), 4, noise)["enhanced"].numpy()
+        want = hostio_ref.postprocess_ref(ref, orig)
+        d = np.abs(out.astype(np.int64) - want.astype(np.int64))
+        assert d.max() <= 1 and (d > 0).mean() < 0.02, (d.max(), (d > 0).mean())
     bare = tmp_path / "bare.pt"
     torch.save(dict(sd), bare)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "benchmark.py"), "--model", str(bare), "--format", "pytorch",
