@@ -50,12 +50,50 @@ def host_cores() -> int:
     return max(1, min(n, 16))
 
 
-def cpu_baseline(variant: str, size: int, steps: int, state_dict, batch: int, budget_s: float = 24.0) -> dict:
+def cpu_baseline(variant: str, size: int, steps: int, state_dict, batch: int, budget_s: float = 24.0, train: bool = False) -> dict:
     """The CPU oracle (a restatement of the reference's PyTorch path, pinned to reference goldens)
     timed on this box's host cores on a bounded sample of the same workload (B=1 and B=min(B,4)):
     enhance(B=1) repeated for about 60 % of budget_s (first call = warm-up unless it alone exceeds the budget), then
     enhance(B=min(batch,4)) for the rest (at least one call).  `value` = the better of the two legs."""
     import oracle
+    if train:
+        # the training step on the CPU oracle (B=1): q-sample, oracle forward, v-pred MSE, PyTorch autograd, clip, AdamW
+        import torch.nn.functional as F
+        from oracle import scheduler_ref as S
+        ncores = host_cores()
+        torch.set_num_threads(ncores)
+        spec = oracle.make_spec(variant, size)
+        params = {k: v.detach().cpu().float().clone().requires_grad_(True) for k, v in state_dict.items()}
+        opt = torch.optim.AdamW(list(params.values()), lr=1e-4, weight_decay=0.01)
+        tab = S.LCMTables.build(rescale_betas_zero_snr=True)
+        g = torch.Generator().manual_seed(1234)
+        low, normal = torch.rand(1, 3, size, size, generator=g) * 2 - 1, torch.rand(1, 3, size, size, generator=g) * 2 - 1
+
+        def step():
+            t = torch.randint(0, 1000, (1,), generator=g)
+            noise = torch.randn(1, 3, size, size, generator=g)
+            opt.zero_grad()
+            pred = oracle.unet_forward(params, spec, torch.cat([S.add_noise(tab, normal, noise, t), low], 1), t)
+            F.mse_loss(pred, S.get_velocity(tab, normal, noise, t)).backward()
+            torch.nn.utils.clip_grad_norm_(list(params.values()), 1.0)
+            opt.step()
+
+        t0 = time.perf_counter()
+        step()
+        first = time.perf_counter() - t0
+        log(f"cpu_baseline (training): first step took {first:.1f} s on {ncores} threads")
+        n, el = 1, first
+        if first < budget_s / 2:
+            n, t0 = 0, time.perf_counter()
+            while True:
+                step()
+                n += 1
+                el = time.perf_counter() - t0
+                if el > budget_s or n >= 10:
+                    break
+        return {"value": round(n / el, 4), "unit": "images/sec", "cores": ncores, "kind": "port",
+                "sample": f"training step on the CPU oracle (B=1, {variant}@{size}, v-pred MSE, autograd, clip, AdamW), {n} step(s), "
+                          f"torch CPU threads={ncores}"}
     ncores = host_cores()
     torch.set_num_threads(ncores)
     spec = oracle.make_spec(variant, size, allow_unpinned=variant in ("tiny", "base"))
@@ -113,9 +151,13 @@ def copy_probe(native, dev, mib: int = 1024, reps: int = 10) -> float:
 
 def train_bench(args, M, dev, rank: int, world: int) -> None:
     """One step = the reference trainer's inner loop (trainer.py:281-338) on `--batch` images per GPU: q-sample,
-    engine forward with kept activations, MSE, engine backward, one flat gradient all-reduce over the ranks,
-    clip_grad_norm_(1.0), AdamW, EMA(0.9999).  Synthetic image pairs resident in HBM."""
-    model = M.LowLightDiffusion(unet_variant=args.variant, image_size=args.image_size, compute_dtype=args.dtype).to(dev).train()
+    engine forward with kept activations, v-prediction MSE (BASELINE config 5: the velocity target of
+    lcm_scheduler.py:282-305), engine backward, one flat gradient all-reduce over the ranks, clip_grad_norm_(1.0), AdamW,
+    EMA(0.9999).  Synthetic image pairs resident in HBM."""
+    sched = M.LCMScheduler(num_train_timesteps=1000, beta_schedule="scaled_linear", prediction_type="v_prediction",
+                           rescale_betas_zero_snr=True)
+    model = M.LowLightDiffusion(unet_variant=args.variant, image_size=args.image_size, compute_dtype=args.dtype,
+                                scheduler=sched).to(dev).train()
     B, S = args.batch, args.image_size
     g = torch.Generator().manual_seed(1234 + rank)
     low = (torch.rand(B, 3, S, S, generator=g) * 2 - 1).to(dev)
@@ -126,7 +168,7 @@ def train_bench(args, M, dev, rank: int, world: int) -> None:
 
     def step():
         opt.zero_grad(set_to_none=True)
-        loss = model.compute_loss(low, normal, loss_type="mse")
+        loss = model.compute_loss(low, normal, loss_type="mse", use_velocity_target=True)
         loss.backward()
         M.all_reduce_gradients(params)
         torch.nn.utils.clip_grad_norm_(params, 1.0)
@@ -153,15 +195,32 @@ def train_bench(args, M, dev, rank: int, world: int) -> None:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     if rank == 0:
+        native = importlib.import_module("cv-diffusion-model_amd._native")
+        extra = {}
+        if not args.no_roofline:
+            # byte model of one training step: the forward's SURVEY.md 8d bytes (every activation is
+            # written once and read once) plus a backward pass that reads each kept activation and each incoming gradient
+            # and writes each outgoing gradient: 3 x llie_algorithmic_bytes.  The whole step (optimiser included) is timed.
+            handle = model.unet._prepare(1, dev)[0]
+            fwd = handle.algorithmic_bytes(B)
+            peak_measured = copy_probe(native, dev)
+            ach = 3 * fwd / (elapsed / args.steps) / 1e9
+            extra["roofline"] = {"bound": "hbm", "kernel": "whole training step (forward + backward + optimiser)",
+                                 "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+                                 "traffic": None, "peak_measured": round(peak_measured, 1),
+                                 "frac_of_measured": round(ach / peak_measured, 4), "alg_bytes_per_step": 3 * fwd,
+                                 "note": "3 x forward algorithmic bytes (SURVEY.md 8d model) / measured step time"}
+        if not args.no_cpu_baseline and world == 1:
+            extra["cpu_baseline"] = cpu_baseline(args.variant, S, 0, model.state_dict(), 1, budget_s=20.0, train=True)
         print(json.dumps({
             "metric": "training images/sec (whole node), 256x256 'small' (BASELINE config 5)",
             "value": round(world * B * args.steps / elapsed, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic (random-init weights, uniform image pairs)",
-            "config": {"workload": f"variant={args.variant}, {S}x{S}, batch={B}/GPU, training step (MSE, AdamW, clip 1.0, EMA), "
+            "config": {"workload": f"variant={args.variant}, {S}x{S}, batch={B}/GPU, training step (v-pred MSE, AdamW, clip 1.0, EMA), "
                                    f"{args.dtype}, {world}xMI355X", "global_batch": world * B,
                        "parallelism": "single GPU" if world == 1 else f"dp{world} (one flat gradient all-reduce)"},
-            "final_loss": round(float(loss.item()), 5)}), flush=True)
+            "final_loss": round(float(loss.item()), 5), **extra}), flush=True)
 
 
 def main() -> None:

@@ -9,7 +9,7 @@ The directory name contains '-', so import it as `import cv_diffusion_model_amd`
 repository root) or `importlib.import_module("cv-diffusion-model_amd")`.
 """
 from .unet import (EfficientUNet, EfficientUNetConfig, create_efficient_unet, InvertedResidualBlock,
-                   LinearAttention, Downsample, Upsample)
+                   LinearAttention, Downsample, Upsample, SqueezeExcitation)
 from .scheduler import LCMScheduler, LCMSchedulerOutput, LCMDenoisingLoop, get_lcm_timesteps
 from .pipeline import LowLightDiffusion, LowLightDiffusionOutput, normalize_image, denormalize_image
 from .sharding import shard_range, enhance_sharded, all_gather_batch, all_reduce_gradients
@@ -20,7 +20,7 @@ from .hostio import (load_checkpoint, extract_state_dict, preprocess_array, post
                      preprocess_device, postprocess_device)
 
 __all__ = [
-    "EfficientUNet", "EfficientUNetConfig", "create_efficient_unet", "InvertedResidualBlock", "LinearAttention",
+    "EfficientUNet", "EfficientUNetConfig", "create_efficient_unet", "InvertedResidualBlock", "LinearAttention", "SqueezeExcitation",
     "Downsample", "Upsample", "LCMScheduler", "LCMSchedulerOutput", "LCMDenoisingLoop", "get_lcm_timesteps", "LowLightDiffusion",
     "LowLightDiffusionOutput", "normalize_image", "denormalize_image", "shard_range", "enhance_sharded",
     "all_gather_batch", "all_reduce_gradients", "register_model", "build_library", "library_path", "load_checkpoint", "extract_state_dict",

@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, "libllie_hip.so")
 
 # enums of include/llie.h
 LLIE_F32, LLIE_F16, LLIE_BF16 = 0, 1, 2
-LLIE_UNET, LLIE_IRB, LLIE_ATTN, LLIE_DOWN, LLIE_UP = 0, 1, 2, 3, 4
+LLIE_UNET, LLIE_IRB, LLIE_ATTN, LLIE_DOWN, LLIE_UP, LLIE_SE = 0, 1, 2, 3, 4, 5
 ERR_ARG, ERR_SHAPE, ERR_CONFIG, ERR_KEY, ERR_NOT_LOADED, ERR_WORKSPACE, ERR_NO_DEVICE = -1, -2, -3, -4, -5, -6, -7
 
 EXPORTS = [
@@ -25,7 +25,7 @@ EXPORTS = [
     "llie_profile_begin", "llie_profile_end", "llie_enhance_workspace_bytes",
     "llie_preprocess_u8", "llie_postprocess_u8", "llie_profile_report", "llie_pw_gemm", "llie_pw_gemm_tile_rows", "llie_dwconv3x3", "llie_dwconv3x3_tiles", "llie_tune",
     "llie_grad_numel", "llie_param_grad_offset", "llie_train_workspace_bytes", "llie_unet_train_forward",
-    "llie_unet_backward", "llie_module_backward", "llie_load_all", "llie_profile_dump", "llie_copy_probe", "llie_refresh_params", "llie_path_bytes",
+    "llie_unet_backward", "llie_module_backward", "llie_load_all", "llie_profile_dump", "llie_copy_probe", "llie_refresh_params", "llie_path_bytes", "llie_time_embed", "llie_debug_irbx_stamps",
 ]
 K_GEMM, K_DW, K_CONV3, K_SE, K_OTHER = 1, 2, 4, 8, 16
 
@@ -94,6 +94,7 @@ def lib() -> C.CDLL:
     L.llie_enhance.argtypes = [vp, vp, vp, vp, C.POINTER(StepCoef), ci, vp, vp, vp, ci, vp, i64, vp]
     L.llie_algorithmic_bytes.argtypes = [vp, ci]
     L.llie_algorithmic_bytes.restype = i64
+    L.llie_time_embed.argtypes = [vp, vp, ci, vp, vp, vp, vp]
     L.llie_path_bytes.argtypes = [vp, ci]
     L.llie_path_bytes.restype = i64
     L.llie_flops.argtypes = [vp, ci]
@@ -105,6 +106,7 @@ def lib() -> C.CDLL:
     L.llie_dwconv3x3.argtypes = [ci, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, vp]
     L.llie_dwconv3x3_tiles.argtypes = [ci, ci]
     L.llie_tune.argtypes = [C.c_char_p, ci]
+    L.llie_debug_irbx_stamps.argtypes = [C.POINTER(C.c_double)]
     L.llie_grad_numel.argtypes = [vp]
     L.llie_grad_numel.restype = i64
     L.llie_param_grad_offset.argtypes = [vp, ci]

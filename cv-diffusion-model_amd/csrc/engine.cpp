@@ -492,6 +492,15 @@ int build_module(llie_ctx* c) {
       if (!gn_ok(g.in_channels)) return LLIE_ERR_CONFIG;
       b.add_attn("", g.in_channels, g.num_attention_heads);
       break;
+    case LLIE_SE: {  // efficient_unet.py:85-94: squeezed = max(1, int(C * 0.25)), both 1x1 convs with bias
+      if (g.in_channels % 32) return LLIE_ERR_CONFIG;
+      IrbW w{};
+      w.hid = w.hid_r = g.in_channels; w.sq = std::max(1, (int)(g.in_channels * 0.25));
+      w.se_w1 = b.mat("fc1.weight", w.sq, w.hid); w.se_b1 = b.f32("fc1.bias", w.sq);
+      w.se_w2 = b.mat("fc2.weight", w.hid, w.sq); w.se_b2 = b.f32("fc2.bias", w.hid);
+      c->irbs.push_back(w);
+      break;
+    }
     case LLIE_DOWN: c->downs.push_back(b.add_conv3("down", g.in_channels)); break;
     case LLIE_UP: c->ups.push_back(b.add_conv3("conv", g.in_channels)); break;
     default: return LLIE_ERR_ARG;
@@ -920,6 +929,28 @@ struct Run {
       if (tape) { tape->stemb = st; tape->film = film; }
     } else if (g.kind == LLIE_ATTN) {
       out = attn(c->attns[0], x0);
+    } else if (g.kind == LLIE_SE) {
+      // SqueezeExcitation.forward (efficient_unet.py:96-100): the 64-pixel (sum, sum of squares) slab of the layout
+      // conversion doubles as the pool partials (every second entry), then the block's own SE kernels and x * gate
+      const IrbW& w = c->irbs[0];
+      const int C = w.hid;
+      const size_t sehid = ar->alloc((size_t)B * w.sq * 4), gate = ar->alloc((size_t)B * C * 4);
+      const size_t semean = ar->alloc((size_t)B * C * 4), zero = ar->alloc((size_t)B * C * 4);
+      out = new_tens(C, H, W, P / kAffineTileRows);
+      if (!dry) {
+        SeArgs e{};
+        e.pool = p<float>(x0.slab); e.ntiles = P / 64; e.pool_stride = 2 * C; e.P = P;
+        e.w1 = wptr(w.se_w1); e.b1 = wptr<float>(w.se_b1); e.w2 = wptr(w.se_w2); e.b2 = wptr<float>(w.se_b2);
+        e.mean = p<float>(semean); e.hid = p<float>(sehid); e.gate = p<float>(gate); e.B = B; e.C = C; e.Cs = w.sq;
+        chk(launch_se_fc1(dt, e, s));
+        chk(launch_se_fc2(dt, e, s));
+        chk(launch_fill_zero(p(zero), (int64_t)B * C * 4, s));
+        AffineAddArgs a{};
+        a.x = p(x0.off); a.as = p<float>(gate); a.ab = p<float>(zero); a.res = nullptr; a.y = p(out.off);
+        a.stats = p<float>(out.slab); a.M = B * P; a.C = C; a.P = P;
+        chk(launch_affine_add(dt, a, s));
+      }
+      rel(sehid); rel(gate); rel(semean); rel(zero);
     } else if (g.kind == LLIE_DOWN) {
       out = conv3(c->downs[0], x0, 0);
     } else {
@@ -1797,7 +1828,7 @@ int llie_unet_backward(llie_ctx* c, const float* d_eps, float* grads, int batch,
 
 int llie_module_backward(llie_ctx* c, const float* x, const float* temb, const float* dy, float* dx, float* dtemb, float* grads,
                          int batch, int H, int W, void* ws, int64_t ws_bytes, llie_stream stream) {
-  if (!c || !x || !dy || !dx || !grads || !ws || batch <= 0 || c->cfg.kind == LLIE_UNET) return LLIE_ERR_ARG;
+  if (!c || !x || !dy || !dx || !grads || !ws || batch <= 0 || c->cfg.kind == LLIE_UNET || c->cfg.kind == LLIE_SE) return LLIE_ERR_ARG;
   if (c->cfg.kind == LLIE_IRB && (!temb || !dtemb)) return LLIE_ERR_ARG;
   if (!c->blob) { set_err("no HIP device"); return LLIE_ERR_NO_DEVICE; }
   int rc = check_loaded(c);
@@ -2030,6 +2061,21 @@ int llie_postprocess_u8(const float* x, int batch, int S, uint8_t* img, int H0, 
   return LLIE_OK;
 }
 
+int llie_time_embed(llie_ctx* c, const int64_t* t, int rows, float* emb, float* temb, float* silu_temb, llie_stream stream) {
+  if (!c || !t || !temb || !silu_temb || rows <= 0 || c->cfg.kind != LLIE_UNET) return LLIE_ERR_ARG;
+  if (int rc = check_loaded(c)) return rc;
+  const llie_config& g = c->cfg;
+  TimeArgs ta{};
+  ta.t = t; ta.rows = rows; ta.dim = g.base_channels; ta.T = g.time_embed_dim;
+  ta.freqs = reinterpret_cast<const float*>(c->blob + c->freqs);
+  ta.w1 = reinterpret_cast<const float*>(c->blob + c->t_w1); ta.b1 = reinterpret_cast<const float*>(c->blob + c->t_b1);
+  ta.w3 = reinterpret_cast<const float*>(c->blob + c->t_w3); ta.b3 = reinterpret_cast<const float*>(c->blob + c->t_b3);
+  ta.temb = temb; ta.silu_temb = silu_temb; ta.emb_out = emb;
+  hipError_t e = launch_time_embed(ta, reinterpret_cast<hipStream_t>(stream));
+  if (e != hipSuccess) { set_err("time_embed: %s", hipGetErrorString(e)); return (int)e; }
+  return LLIE_OK;
+}
+
 int llie_copy_probe(const void* src, void* dst, int64_t bytes, llie_stream stream) {
   if (!src || !dst || bytes <= 0) return LLIE_ERR_ARG;
   hipError_t e = launch_copy_probe(src, dst, bytes, reinterpret_cast<hipStream_t>(stream));
@@ -2050,6 +2096,7 @@ int llie_tune(const char* knob, int value) {
   if (!strcmp(knob, "irbx")) { g_use_irbx = value != 0; return LLIE_OK; }
   if (!strcmp(knob, "irbx_dbuf")) { irbx_tune(value, 0); return LLIE_OK; }
   if (!strcmp(knob, "irbx_tiles")) { irbx_tune(-1, value); return LLIE_OK; }
+  if (!strcmp(knob, "irbx_stamp")) { irbx_stamp(value); return LLIE_OK; }
   if (!strcmp(knob, "gemm_ablate")) { pw_gemm_debug(value); return LLIE_OK; }
   if (!strcmp(knob, "dw_ablate")) { dwconv_debug(value); return LLIE_OK; }
   if (!strcmp(knob, "dw_swap")) { dwconv_swap(value); return LLIE_OK; }
@@ -2057,6 +2104,14 @@ int llie_tune(const char* knob, int value) {
   if (!strcmp(knob, "enhance_split")) { g_enhance_split = value; return LLIE_OK; }
   if (!strcmp(knob, "wgrad_target")) { wgrad_set_target(value); return LLIE_OK; }
   return LLIE_ERR_ARG;
+}
+
+// diagnostic: mean per-wave cycles of the last stamped expand_dw launch (llie_tune("irbx_stamp", 1)); synchronises
+int llie_debug_irbx_stamps(double* out4) {
+  if (!out4) return LLIE_ERR_ARG;
+  hipError_t e = hipDeviceSynchronize();
+  if (e == hipSuccess) e = irbx_stamp_fetch(out4);
+  return e == hipSuccess ? LLIE_OK : LLIE_ERR_ARG;
 }
 
 int llie_profile_begin(llie_ctx* c, int class_mask) {

@@ -19,6 +19,7 @@
 // Both kernels write fixed per-tile partial sums (no atomics), so results stay bitwise independent of the batch.
 #include <string>
 #include <type_traits>
+#include <vector>
 
 #include "common.h"
 #include "kernels.h"
@@ -31,6 +32,11 @@ template <typename T>
 __device__ __forceinline__ f32x16 mfma16(typename Elem<T>::vec_t a, typename Elem<T>::vec_t b, f32x16 c) {
   if constexpr (std::is_same<T, half_t>::value) return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
   else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float dot2_bf16(uint32_t a, uint32_t b, float c) {
+  return __builtin_amdgcn_fdot2_f32_bf16(*reinterpret_cast<const bf16x2_t*>(&a), *reinterpret_cast<const bf16x2_t*>(&b), c, false);
 }
 
 // a' = relu6(a * s + b) on one 16-byte operand slice (8 channels); sc / sh point at the slice's 8 scale / shift
@@ -51,19 +57,19 @@ __device__ __forceinline__ typename Elem<T>::vec_t activate8(typename Elem<T>::v
 
 // ---------------------------------------------------------------------------------------------
 // (1) statistics of h1 = W1 . relu6(aff1(x)) without storing it.
-//   grid (P / RP, 1, B); 4 waves = PS pixel groups x NS channel groups; a wave owns NBW = Chid / 32 / NS
-//   32-channel blocks (their weight slices stay in registers) and RP / PS pixels.
-//   MFMA roles: A = pixels (rows), B = weights (columns): a lane holds 16 pixels of ONE channel, so the
-//   per-channel sums are plain register adds.
-template <typename T, int KS, int NBW, int NS>
-__global__ void __launch_bounds__(256) expand_stats_kernel(const IrbxArgs a, const int RP) {
-  constexpr int K = 16 * KS, PS = 4 / NS;
+//   grid (P / RP, 1, B): a workgroup walks RP pixels of one image in steps of 128.  Each step's x rows are activated
+//   ONCE, cooperatively, into a double-buffered LDS tile (one barrier per step); wave w owns the NBW = Chid / 128
+//   32-channel blocks [w * NBW, (w + 1) * NBW) -- their weight slices stay in registers -- and multiplies them with all
+//   four 32-pixel blocks of the tile.  MFMA roles: A = pixels (rows), B = weights (columns): a lane holds 16 pixels of
+//   ONE channel, so the per-channel sums are plain register adds and no accumulator is ever stored.
+template <typename T, int KS, int NBW>
+__global__ void __launch_bounds__(256, 2) expand_stats_kernel(const IrbxArgs a, const int RP) {
+  constexpr int K = 16 * KS, XP = (K + 8) * 2;  // LDS pixel pitch in bytes: conflict-free ds_read_b128
   typedef typename Elem<T>::vec_t vec_t;
-  __shared__ float red[4][2][NBW * 32];
+  __shared__ __align__(16) unsigned char sA[2][128 * XP];
   __shared__ __align__(16) float aff1[2][K];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n = lane & 31, h = lane >> 5;
-  const int pg = wave % PS, ng = wave / PS;
   const int b = blockIdx.z, tile = blockIdx.x;
   const int P = a.H * a.W;
   const T* x0 = reinterpret_cast<const T*>(a.x0) + (size_t)b * P * a.c0;
@@ -74,71 +80,74 @@ __global__ void __launch_bounds__(256) expand_stats_kernel(const IrbxArgs a, con
 #pragma unroll
   for (int j = 0; j < NBW; ++j)
 #pragma unroll
-    for (int s = 0; s < KS; ++s) wf[j][s] = ld_vec<T>(w1 + (size_t)((ng * NBW + j) * 32 + n) * K + 16 * s + 8 * h);
+    for (int s = 0; s < KS; ++s) wf[j][s] = ld_vec<T>(w1 + (size_t)((wave * NBW + j) * 32 + n) * K + 16 * s + 8 * h);
   for (int i = tid; i < K; i += 256) {
     aff1[0][i] = a.as1[(size_t)b * K + i];
     aff1[1][i] = a.ab1[(size_t)b * K + i];
   }
-  __syncthreads();
   float s1[NBW], s2[NBW];
 #pragma unroll
   for (int j = 0; j < NBW; ++j) s1[j] = s2[j] = 0.f;
 
-  const int nblk = RP / PS / 32;  // 32-pixel blocks of this wave
-  const int p_first = tile * RP + pg * (RP / PS);
-  auto load = [&](int blk, vec_t (&v)[KS]) {
-    const size_t pix = (size_t)p_first + blk * 32 + n;
+  // cooperative load: vector v = tid + j*256 of a step -> pixel v / (2 KS), channel vector v % (2 KS)
+  const int nsteps = RP / 128;
+  const size_t p_first = (size_t)tile * RP;
+  vec_t raw[KS];
+  auto load = [&](int step) {
 #pragma unroll
-    for (int s = 0; s < KS; ++s) {
-      const int k = 16 * s + 8 * h;
-      v[s] = k < a.c0 ? ld_vec<T>(x0 + pix * a.c0 + k) : ld_vec<T>(x1 + pix * a.c1 + (k - a.c0));
+    for (int j = 0; j < KS; ++j) {
+      const int v = tid + j * 256;
+      const size_t pix = p_first + (size_t)step * 128 + v / (2 * KS);
+      const int k = (v % (2 * KS)) * 8;
+      raw[j] = k < a.c0 ? ld_vec<T>(x0 + pix * a.c0 + k) : ld_vec<T>(x1 + pix * a.c1 + (k - a.c0));
     }
   };
-  vec_t cur[KS], nxt[KS];
-  load(0, cur);
-  for (int blk = 0; blk < nblk; ++blk) {
-    if (blk + 1 < nblk) load(blk + 1, nxt);
-    vec_t af[KS];
+  load(0);
+  __syncthreads();  // aff1 staged
+  for (int step = 0; step < nsteps; ++step) {
+    unsigned char* buf = sA[step & 1];
 #pragma unroll
-    for (int s = 0; s < KS; ++s) af[s] = activate8<T>(cur[s], &aff1[0][16 * s + 8 * h], &aff1[1][16 * s + 8 * h]);
-#pragma unroll
-    for (int j = 0; j < NBW; ++j) {
-      f32x16 acc;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-#pragma unroll
-      for (int s = 0; s < KS; ++s) acc = mfma16<T>(af[s], wf[j][s], acc);
-      float t1 = 0.f, t2 = 0.f;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        t1 += acc[r];
-        t2 += acc[r] * acc[r];
-      }
-      s1[j] += t1;
-      s2[j] += t2;
+    for (int j = 0; j < KS; ++j) {
+      const int v = tid + j * 256;
+      const int k = (v % (2 * KS)) * 8;
+      *reinterpret_cast<vec_t*>(buf + (v / (2 * KS)) * XP + k * 2) = activate8<T>(raw[j], &aff1[0][k], &aff1[1][k]);
     }
+    if (step + 1 < nsteps) load(step + 1);
+    __syncthreads();  // tile `step` complete; the other buffer (read during step - 1) is free for step + 1
 #pragma unroll
-    for (int s = 0; s < KS; ++s) cur[s] = nxt[s];
+    for (int pb = 0; pb < 4; ++pb) {
+      vec_t af[KS];
+#pragma unroll
+      for (int s = 0; s < KS; ++s) af[s] = *reinterpret_cast<const vec_t*>(buf + (pb * 32 + n) * XP + (16 * s + 8 * h) * 2);
+#pragma unroll
+      for (int j = 0; j < NBW; ++j) {
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) acc = mfma16<T>(af[s], wf[j][s], acc);
+        float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          t1 += acc[r];
+          t2 += acc[r] * acc[r];
+        }
+        s1[j] += t1;
+        s2[j] += t2;
+      }
+    }
   }
-  // lane halves hold different pixel rows of the same channel; then the PS pixel groups, in wave order
+  // lane halves hold different pixel rows of the same channel; every wave owns its channels outright
+  const int ntiles = P / RP;
 #pragma unroll
   for (int j = 0; j < NBW; ++j) {
     s1[j] += __shfl_xor(s1[j], 32, 64);
     s2[j] += __shfl_xor(s2[j], 32, 64);
     if (h == 0) {
-      red[wave][0][j * 32 + n] = s1[j];
-      red[wave][1][j * 32 + n] = s2[j];
+      const int c = (wave * NBW + j) * 32 + n;
+      a.stats[((size_t)(b * ntiles + tile) * 2 + 0) * a.Chid + c] = s1[j];
+      a.stats[((size_t)(b * ntiles + tile) * 2 + 1) * a.Chid + c] = s2[j];
     }
-  }
-  __syncthreads();
-  const int ntiles = P / RP;
-  for (int i = tid; i < 2 * a.Chid; i += 256) {
-    const int which = i / a.Chid, c = i % a.Chid;
-    const int g = c / (NBW * 32), cc = c % (NBW * 32);
-    float t = 0.f;
-#pragma unroll
-    for (int q = 0; q < PS; ++q) t += red[g * PS + q][which][cc];
-    a.stats[((size_t)(b * ntiles + tile) * 2 + which) * a.Chid + c] = t;
   }
 }
 
@@ -154,13 +163,16 @@ constexpr int kXNPB = 6;
 // the xor spreads the epilogue's ds_write_b128 (8 consecutive pixels, same slot) over 4 slots.
 __device__ __forceinline__ int xh_off(int q, int slot) { return q * 128 + ((slot ^ (q & 3)) << 4); }
 
-template <typename T, int KS, bool DBUF>
+// STAMP = diagnostic build (llie_tune("irbx_stamp", 1)): s_memtime around the phases, summed per wave into a.dbg
+// ([workgroup][wave][4] = {tile prologue, MFMA phase, barrier wait, depthwise phase} cycles); never used in production.
+template <typename T, int KS, bool DBUF, bool STAMP = false>
 __global__ void __launch_bounds__(256, 2) expand_dw_kernel(const IrbxArgs a, const int tiles_per_wg, const int chunks_per_wg) {
   constexpr int K = 16 * KS;
   constexpr int XP = (K + 8) * 2;                        // sX pixel pitch in bytes (80 / 144 / 208 / 272: conflict-free ds_read_b128)
   constexpr int XV = kXNPX * 2 * KS;                     // 16-byte vectors of one x halo tile
   constexpr int XPT = (XV + 255) / 256;                  // ... per thread
   constexpr int SH_BYTES = kXNPB * 32 * 128;
+  constexpr bool PREF = KS <= 2;                         // next tile's x prefetched into registers (36 VGPRs at KS = 6: not worth a spill)
   typedef typename Elem<T>::vec_t vec_t;
   extern __shared__ __align__(16) unsigned char smem[];
   // [sH: (DBUF ? 2 : 1) x 192 x 128 B][sX: 192 x XP][wds: 9 x Chid T][aff2: 2 x Chid fp32][aff1: 2 x K fp32][red: 2 x 4 x 64 fp32]
@@ -223,9 +235,26 @@ __global__ void __launch_bounds__(256, 2) expand_dw_kernel(const IrbxArgs a, con
       }
     }
   };
-  if (tile_first < tile_last) load_tile(tile_first);
+  if (PREF && tile_first < tile_last) load_tile(tile_first);
+  // weight slices (A operand) of the chunk about to run.  They are always fetched one depthwise phase ahead and BEFORE
+  // that phase's stores: the wait in front of the MFMAs then leaves the (younger) stores in flight instead of draining them.
+  vec_t wf[KS];
+  auto load_wf = [&](int chunk) {
+#pragma unroll
+    for (int s = 0; s < KS; ++s) wf[s] = ld_vec<T>(w1 + (size_t)(chunk * 64 + chb * 32 + n) * K + 16 * s + 8 * h);
+  };
+  load_wf(chunk0);
   __syncthreads();  // constants staged
 
+  unsigned long long tk[4] = {0, 0, 0, 0}, t_prev = 0;
+  auto stamp = [&](int slot) {
+    if constexpr (STAMP) {
+      const unsigned long long now = __builtin_amdgcn_s_memtime();
+      if (slot >= 0) tk[slot] += now - t_prev;
+      t_prev = now;
+    }
+  };
+  stamp(-1);
   int par = 0;  // sH / red buffer parity (DBUF)
   int pend_tile = -1, pend_chunk = 0, pend_par = 0;  // pool partial waiting for its cross-wave sum
   auto flush_pool = [&]() {  // after a barrier that follows the depthwise phase which wrote red[pend_par]
@@ -242,6 +271,7 @@ __global__ void __launch_bounds__(256, 2) expand_dw_kernel(const IrbxArgs a, con
     const int y0 = ty * kXT_H, x0p = tx * kXT_W;
     // ---- activate this tile's x (norm1 + ReLU6) into sX, prefetch the next tile.  Every wave is past the last
     // MFMA phase of the previous tile here (the barrier that follows it), so sX is free.
+    if (!PREF) load_tile(tile);
 #pragma unroll
     for (int j = 0; j < XPT; ++j) {
       const int v = tid + j * 256;
@@ -250,7 +280,7 @@ __global__ void __launch_bounds__(256, 2) expand_dw_kernel(const IrbxArgs a, con
         *reinterpret_cast<vec_t*>(sX + q * XP + k * 2) = activate8<T>(raw[j], aff1 + k, aff1 + K + k);
       }
     }
-    if (tile + 1 < tile_last) load_tile(tile + 1);
+    if (PREF && tile + 1 < tile_last) load_tile(tile + 1);
     // validity of this lane's three halo pixels (zero padding of the depthwise input)
     bool ok[3];
 #pragma unroll
@@ -261,6 +291,7 @@ __global__ void __launch_bounds__(256, 2) expand_dw_kernel(const IrbxArgs a, con
     }
     __syncthreads();
     if (!DBUF) flush_pool();
+    stamp(0);
 
     for (int chunk = chunk0; chunk < chunk1; ++chunk) {
       unsigned char* buf = sH + (DBUF ? par * SH_BYTES : 0);
@@ -270,9 +301,6 @@ __global__ void __launch_bounds__(256, 2) expand_dw_kernel(const IrbxArgs a, con
       }
       // ---- MFMA: h1^T block (32 channels x 32 pixels) x 3 pixel blocks
       const int ch0 = chunk * 64 + chb * 32;
-      vec_t wf[KS];
-#pragma unroll
-      for (int s = 0; s < KS; ++s) wf[s] = ld_vec<T>(w1 + (size_t)(ch0 + n) * K + 16 * s + 8 * h);
       // aff2 of this lane's 16 accumulator channels: ch0 + 8g + 4h + e
       f32x4 sc2[4], sh2[4];
 #pragma unroll
@@ -280,15 +308,32 @@ __global__ void __launch_bounds__(256, 2) expand_dw_kernel(const IrbxArgs a, con
         sc2[g] = *reinterpret_cast<const f32x4*>(aff2 + ch0 + 8 * g + 4 * h);
         sh2[g] = *reinterpret_cast<const f32x4*>(aff2 + a.Chid + ch0 + 8 * g + 4 * h);
       }
+      constexpr int NACC = KS <= 2 ? 3 : 1;  // accumulators in flight: all three pixel blocks, or one at a time (registers)
+      f32x16 accs[NACC];
+      if constexpr (NACC == 3) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          const int q = (pxg * 3 + i) * 32 + n;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) accs[i][r] = 0.f;
+#pragma unroll
+          for (int s = 0; s < KS; ++s)
+            accs[i] = mfma16<T>(wf[s], *reinterpret_cast<const vec_t*>(sX + q * XP + (16 * s + 8 * h) * 2), accs[i]);
+        }
+        load_wf(chunk + 1 < chunk1 ? chunk + 1 : chunk0);  // next chunk (or the next tile's first): see above
+      }
 #pragma unroll
       for (int i = 0; i < 3; ++i) {
         const int q = (pxg * 3 + i) * 32 + n;
-        f32x16 acc;
+        if constexpr (NACC == 1) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+          for (int r = 0; r < 16; ++r) accs[0][r] = 0.f;
 #pragma unroll
-        for (int s = 0; s < KS; ++s)
-          acc = mfma16<T>(wf[s], *reinterpret_cast<const vec_t*>(sX + q * XP + (16 * s + 8 * h) * 2), acc);
+          for (int s = 0; s < KS; ++s)
+            accs[0] = mfma16<T>(wf[s], *reinterpret_cast<const vec_t*>(sX + q * XP + (16 * s + 8 * h) * 2), accs[0]);
+          if (i == 2) load_wf(chunk + 1 < chunk1 ? chunk + 1 : chunk0);
+        }
+        const f32x16 acc = accs[NACC == 3 ? i : 0];
         // epilogue: aff2 + ReLU6, zero outside the image (the conv's padding), pack, exchange lane halves so
         // that each lane owns 8 consecutive channels, two ds_write_b128
         uint32_t pk[4][2];
@@ -316,8 +361,10 @@ __global__ void __launch_bounds__(256, 2) expand_dw_kernel(const IrbxArgs a, con
         *reinterpret_cast<u32x4*>(buf + xh_off(q, chb * 4 + 2 * h)) = lo;
         *reinterpret_cast<u32x4*>(buf + xh_off(q, chb * 4 + 2 * h + 1)) = hi2;
       }
+      stamp(1);
       __syncthreads();
       if (DBUF) flush_pool();
+      stamp(2);
       // ---- depthwise 3x3 on the LDS tile: thread = 8 channels x 4 output rows of one column
       {
         const int c8 = chunk * 64 + cl * 8;
@@ -328,12 +375,22 @@ __global__ void __launch_bounds__(256, 2) expand_dw_kernel(const IrbxArgs a, con
 #pragma unroll
         for (int e = 0; e < 8; ++e) acc3[0][e] = acc3[1][e] = acc3[2][e] = psum[e] = 0.f;
         T* orow = out + ((size_t)(y0 + rh * 4) * a.W + x0p + cx) * a.Chid + c8;
+        // rows are read one ahead of their use; the scheduling fences keep the compiler from hoisting all 18 reads
+        // (72 registers) in front of the arithmetic, which costs a wave of occupancy or spills
+        vec_t fn[3];
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) fn[kx] = *reinterpret_cast<const vec_t*>(buf + xh_off((rh * 4) * kXH_W + cx + kx, cl));
 #pragma unroll
         for (int r = 0; r < 6; ++r) {  // halo rows rh*4 + r
-          const int qrow = (rh * 4 + r) * kXH_W + cx;
           vec_t f[3];
 #pragma unroll
-          for (int kx = 0; kx < 3; ++kx) f[kx] = *reinterpret_cast<const vec_t*>(buf + xh_off(qrow + kx, cl));
+          for (int kx = 0; kx < 3; ++kx) f[kx] = fn[kx];
+          if (r < 5) {
+            const int qrow = (rh * 4 + r + 1) * kXH_W + cx;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) fn[kx] = *reinterpret_cast<const vec_t*>(buf + xh_off(qrow + kx, cl));
+          }
+          __builtin_amdgcn_sched_barrier(0);
           float* a2 = acc3[(r + 1) % 3];  // ky = 2 -> output row r-2
           float* a1 = acc3[(r + 2) % 3];  // ky = 1 -> output row r-1
           float* a0 = acc3[r % 3];        // ky = 0 -> output row r
@@ -352,24 +409,47 @@ __global__ void __launch_bounds__(256, 2) expand_dw_kernel(const IrbxArgs a, con
               }
             }
           } else {
+            // bf16 has no mixed-precision FMA; v_dot2c_f32_bf16 on a data word with one half masked off is one: weights stay
+            // packed, no conversions (acc += w.lo * f.lo + w.hi * 0)
 #pragma unroll
-            for (int kx = 0; kx < 3; ++kx)
+            for (int kx = 0; kx < 3; ++kx) {
+              const u32x4 fq = reinterpret_cast<const u32x4&>(f[kx]);
+              const u32x4 w2 = reinterpret_cast<const u32x4&>(w[6 + kx]);
+              const u32x4 w1v = reinterpret_cast<const u32x4&>(w[3 + kx]);
+              const u32x4 w0 = reinterpret_cast<const u32x4&>(w[0 + kx]);
 #pragma unroll
-              for (int e = 0; e < 8; ++e) {
-                if (r >= 2) a2[e] += (float)w[6 + kx][e] * (float)f[kx][e];
-                if (r >= 1 && r <= 4) a1[e] += (float)w[3 + kx][e] * (float)f[kx][e];
-                if (r <= 3) a0[e] += (float)w[0 + kx][e] * (float)f[kx][e];
+              for (int q4 = 0; q4 < 4; ++q4) {
+                const uint32_t flo = fq[q4] & 0x0000FFFFu, fhi = fq[q4] & 0xFFFF0000u;
+                if (r >= 2) { a2[2 * q4] = dot2_bf16(w2[q4], flo, a2[2 * q4]); a2[2 * q4 + 1] = dot2_bf16(w2[q4], fhi, a2[2 * q4 + 1]); }
+                if (r >= 1 && r <= 4) { a1[2 * q4] = dot2_bf16(w1v[q4], flo, a1[2 * q4]); a1[2 * q4 + 1] = dot2_bf16(w1v[q4], fhi, a1[2 * q4 + 1]); }
+                if (r <= 3) { a0[2 * q4] = dot2_bf16(w0[q4], flo, a0[2 * q4]); a0[2 * q4 + 1] = dot2_bf16(w0[q4], fhi, a0[2 * q4 + 1]); }
               }
+            }
           }
           if (r >= 2) {
             vec_t ov = f32_to_vec<T>(a2);
             st_vec<T>(orow + (size_t)(r - 2) * a.W * a.Chid, ov);
+            if constexpr (std::is_same<T, half_t>::value) {
+              const u32x4 oq = reinterpret_cast<const u32x4&>(ov);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-              psum[e] += (float)ov[e];
-              a2[e] = 0.f;
+              for (int q4 = 0; q4 < 4; ++q4) {  // psum += 1.0h * ov: the rounded value, one instruction per element
+                fma_mix_lo(psum[2 * q4], 0x3C003C00u, oq[q4]);
+                fma_mix_hi(psum[2 * q4 + 1], 0x3C003C00u, oq[q4]);
+              }
+#pragma unroll
+              for (int e = 0; e < 8; ++e) a2[e] = 0.f;
+            } else {
+              const u32x4 oq = reinterpret_cast<const u32x4&>(ov);
+#pragma unroll
+              for (int q4 = 0; q4 < 4; ++q4) {  // psum += 1.0 * ov (0x3F80 = bf16 one)
+                psum[2 * q4] = dot2_bf16(0x3F803F80u, oq[q4] & 0x0000FFFFu, psum[2 * q4]);
+                psum[2 * q4 + 1] = dot2_bf16(0x3F803F80u, oq[q4] & 0xFFFF0000u, psum[2 * q4 + 1]);
+              }
+#pragma unroll
+              for (int e = 0; e < 8; ++e) a2[e] = 0.f;
             }
           }
+          __builtin_amdgcn_sched_barrier(0);
         }
         // SE pool partial of this (tile, chunk): lanes -> per-wave channel sums -> red[par][wave][64]
         if (a.pool) {
@@ -378,6 +458,14 @@ __global__ void __launch_bounds__(256, 2) expand_dw_kernel(const IrbxArgs a, con
         }
       }
       if (DBUF) par ^= 1;
+      stamp(3);
+    }
+  }
+  if constexpr (STAMP) {
+    if (a.dbg && lane == 0) {
+      const size_t wg = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a.dbg[(wg * 4 + wave) * 4 + i] = tk[i];
     }
   }
   if (a.pool) {
@@ -402,27 +490,41 @@ int irbx_stats_rows(int P) {
   return rp;
 }
 
-static int g_irbx_dbuf = 1, g_irbx_tiles = 4;
+static int g_irbx_dbuf = 1, g_irbx_tiles = 4, g_irbx_stamp = 0;
+static unsigned long long* g_irbx_dbg = nullptr;
+static size_t g_irbx_dbg_n = 0;  // entries of the last stamped launch
+void irbx_stamp(int v) { g_irbx_stamp = v; }
+// mean cycles per wave of the last stamped launch: out[4] = {tile prologue, MFMA phase, barrier wait, depthwise phase}
+hipError_t irbx_stamp_fetch(double* out) {
+  if (!g_irbx_dbg || !g_irbx_dbg_n) return hipErrorInvalidValue;
+  std::vector<unsigned long long> h(g_irbx_dbg_n);
+  hipError_t e = hipMemcpy(h.data(), g_irbx_dbg, g_irbx_dbg_n * 8, hipMemcpyDeviceToHost);
+  if (e != hipSuccess) return e;
+  for (int i = 0; i < 4; ++i) out[i] = 0.0;
+  for (size_t i = 0; i < g_irbx_dbg_n; ++i) out[i & 3] += (double)h[i];
+  for (int i = 0; i < 4; ++i) out[i] /= (double)(g_irbx_dbg_n / 4);
+  return hipSuccess;
+}
 void irbx_tune(int dbuf, int tiles_per_wg) {
   if (dbuf >= 0) g_irbx_dbuf = dbuf;
   if (tiles_per_wg > 0) g_irbx_tiles = tiles_per_wg;
 }
 
-template <typename T, int KS, int NBW, int NS>
+template <typename T, int KS, int NBW>
 static hipError_t launch_stats_cfg(const IrbxArgs& a, hipStream_t s) {
   const int P = a.H * a.W, RP = irbx_stats_rows(P);
   static const std::string name = std::string("expand_stats_kernel<") + TypeName<T>::value + ", " + std::to_string(KS) + ", " +
-                                  std::to_string(NBW) + ", " + std::to_string(NS) + ">";
+                                  std::to_string(NBW) + ">";
   note_kernel(name.c_str());
-  hipLaunchKernelGGL((expand_stats_kernel<T, KS, NBW, NS>), dim3(P / RP, 1, a.B), dim3(256), 0, s, a, RP);
+  hipLaunchKernelGGL((expand_stats_kernel<T, KS, NBW>), dim3(P / RP, 1, a.B), dim3(256), 0, s, a, RP);
   return hipGetLastError();
 }
 template <typename T>
 static hipError_t launch_stats_t(const IrbxArgs& a, hipStream_t s) {
   const int Cin = a.c0 + a.c1;
-  if (Cin == 32 && a.Chid == 128) return launch_stats_cfg<T, 2, 4, 1>(a, s);
-  if (Cin == 64 && a.Chid == 256) return launch_stats_cfg<T, 4, 4, 2>(a, s);
-  if (Cin == 96 && a.Chid == 384) return launch_stats_cfg<T, 6, 3, 4>(a, s);
+  if (Cin == 32 && a.Chid == 128) return launch_stats_cfg<T, 2, 1>(a, s);
+  if (Cin == 64 && a.Chid == 256) return launch_stats_cfg<T, 4, 2>(a, s);
+  if (Cin == 96 && a.Chid == 384) return launch_stats_cfg<T, 6, 3>(a, s);
   return hipErrorInvalidValue;
 }
 hipError_t launch_expand_stats(int dtype, const IrbxArgs& a, hipStream_t s) {
@@ -452,7 +554,30 @@ static hipError_t launch_dw_cfg(const IrbxArgs& a, hipStream_t s) {
   static const std::string name = std::string("expand_dw_kernel<") + TypeName<T>::value + ", " + std::to_string(KS) + ", " +
                                   (DBUF ? "1" : "0") + ">";
   note_kernel(name.c_str());
-  hipLaunchKernelGGL((expand_dw_kernel<T, KS, DBUF>), dim3(ntiles / tpw, nchunks / cpw, a.B), dim3(256), lds, s, a, tpw, cpw);
+  const dim3 grid(ntiles / tpw, nchunks / cpw, a.B);
+  if constexpr (KS == 2 && std::is_same<T, half_t>::value) {
+    if (g_irbx_stamp) {  // diagnostic build with in-kernel cycle stamps
+      const size_t n = (size_t)grid.x * grid.y * grid.z * 16;
+      if (n > g_irbx_dbg_n || !g_irbx_dbg) {
+        if (g_irbx_dbg) (void)hipFree(g_irbx_dbg);
+        hipError_t e = hipMalloc(reinterpret_cast<void**>(&g_irbx_dbg), n * 8);
+        if (e != hipSuccess) return e;
+      }
+      g_irbx_dbg_n = n;
+      IrbxArgs b = a;
+      b.dbg = g_irbx_dbg;
+      static bool attr2 = false;
+      if (!attr2) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&expand_dw_kernel<T, KS, DBUF, true>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+        if (e != hipSuccess) return e;
+        attr2 = true;
+      }
+      hipLaunchKernelGGL((expand_dw_kernel<T, KS, DBUF, true>), grid, dim3(256), lds, s, b, tpw, cpw);
+      return hipGetLastError();
+    }
+  }
+  hipLaunchKernelGGL((expand_dw_kernel<T, KS, DBUF>), grid, dim3(256), lds, s, a, tpw, cpw);
   return hipGetLastError();
 }
 template <typename T>

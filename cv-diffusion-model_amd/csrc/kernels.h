@@ -120,7 +120,10 @@ struct IrbxArgs {
   void* out; float* pool;                        // expand_dw outputs
   float* stats;                                  // expand_stats output
   int B, H, W, Chid;
+  unsigned long long* dbg;                       // diagnostic builds only (irbx_stamp)
 };
+void irbx_stamp(int v);
+hipError_t irbx_stamp_fetch(double* out4);
 bool irbx_supported(int dtype, int Cin, int c0, int Chid, int H, int W);
 int irbx_pool_tiles(int H, int W);
 int irbx_stats_rows(int P);
@@ -137,6 +140,7 @@ void dwconv_debug(int v);  // timing ablations (bit 0: no MACs, bit 1: no activa
 //   fc2: gate[b][c] = sigmoid(b2[c] + sum_j W2[c][j] * hid[b][j])
 struct SeArgs {
   const float* pool; int ntiles; int P;
+  int pool_stride;                  // floats between consecutive tile entries of one image (0 = C)
   const void* w1; const float* b1;  // [Cs][C] T
   const void* w2; const float* b2;  // [C][Cs] T
   float* mean;                      // [B][C] scratch
@@ -158,6 +162,7 @@ struct TimeArgs {
   const float* w1; const float* b1; const float* w3; const float* b3;
   float* temb;        // [rows][T]
   float* silu_temb;   // [rows][T]
+  float* emb_out;     // optional [rows][dim]: the sinusoidal embedding itself
 };
 hipError_t launch_time_embed(const TimeArgs& a, hipStream_t s);
 struct FilmArgs {

@@ -118,8 +118,9 @@ __global__ void __launch_bounds__(256) se_pool_kernel(const SeArgs a) {
   const int c = blockIdx.x * 64 + c4 * 4, b = blockIdx.y;
   f32x4 s = {0.f, 0.f, 0.f, 0.f};
   if (c < a.C) {
-    const float* p = a.pool + (size_t)b * a.ntiles * a.C + c;
-    for (int t = tg; t < a.ntiles; t += 16) s += *reinterpret_cast<const f32x4*>(p + (size_t)t * a.C);
+    const int ps = a.pool_stride ? a.pool_stride : a.C;
+    const float* p = a.pool + (size_t)b * a.ntiles * ps + c;
+    for (int t = tg; t < a.ntiles; t += 16) s += *reinterpret_cast<const f32x4*>(p + (size_t)t * ps);
   }
 #pragma unroll
   for (int e = 0; e < 4; ++e) part[tg][c4 * 4 + e] = s[e];
@@ -240,6 +241,10 @@ __global__ void __launch_bounds__(256) time_embed_kernel(const TimeArgs a) {
     const float arg = t * a.freqs[i];  // fp32 product like t[:, None].float() * freqs[None] (:74)
     emb[i] = cosf(arg);
     emb[half + i] = sinf(arg);
+    if (a.emb_out) {
+      a.emb_out[(size_t)r * a.dim + i] = emb[i];
+      a.emb_out[(size_t)r * a.dim + half + i] = emb[half + i];
+    }
   }
   __syncthreads();
   for (int j = tid; j < a.T; j += 256) {

@@ -374,6 +374,22 @@ class Upsample(_NativeModule):
         return self._run_module(x, None, lambda h, w: (self.channels, h * 2, w * 2))
 
 
+class SqueezeExcitation(_NativeModule):
+    """efficient_unet.py:79-100 (reduction 0.25, ReLU6 -> sigmoid; `fc1` / `fc2` 1x1 convs with bias).  Inside the network
+    SE runs fused into the block's kernels; this module exposes the same kernels for operator-level tests (forward only)."""
+
+    def __init__(self, channels: int, reduction: float = 0.25, quantization_friendly: bool = True):
+        if reduction != 0.25 or not quantization_friendly:
+            raise NotImplementedError("only the configuration instantiated by EfficientUNet is supported")
+        super().__init__(_module_cfg(N.LLIE_SE, channels, channels))
+        self.channels = channels
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if self._wants_grad(x):
+            raise NotImplementedError("the stand-alone SqueezeExcitation operator is forward-only; run under torch.no_grad()")
+        return self._run_module_raw(x, None, lambda h, w: (self.channels, h, w))
+
+
 class EfficientUNet(_NativeModule):
     """efficient_unet.py:387-628: same state_dict (321 keys for small@256), forward(x, timestep)."""
 
@@ -402,6 +418,22 @@ class EfficientUNet(_NativeModule):
         nbytes = h.enhance_workspace_bytes(batch, enhance_steps) if enhance_steps else h.workspace_bytes(batch)
         ws = self._workspace(h, nbytes, device)
         return h, ws, ws.numel()
+
+    @torch.no_grad()
+    def time_embedding(self, timestep: torch.Tensor):
+        """SinusoidalPosEmb and time_mlp on their own (efficient_unet.py:60-76, 412-417): -> (emb [B, base_channels],
+        t_emb [B, time_embed_dim]) as the engine's time kernel computes them (operator-level tests)."""
+        h = self._handle(resolve_compute_dtype(self.compute_dtype))
+        dev = self._device()
+        t = timestep.to(device=dev, dtype=torch.long).contiguous()
+        n = t.numel()
+        emb = torch.empty(n, self.config.base_channels, dtype=torch.float32, device=dev)
+        temb = torch.empty(n, self.config.time_embed_dim, dtype=torch.float32, device=dev)
+        stemb = torch.empty_like(temb)
+        with torch.cuda.device(dev):
+            N.check(N.lib().llie_time_embed(h.h, t.data_ptr(), n, emb.data_ptr(), temb.data_ptr(), stemb.data_ptr(),
+                                            torch.cuda.current_stream(dev).cuda_stream), "time_embedding")
+        return emb, temb
 
     def forward_split(self, latents: torch.Tensor, cond: torch.Tensor, timestep: torch.Tensor,
                       uniform_t: bool = False, out: Optional[torch.Tensor] = None) -> torch.Tensor:

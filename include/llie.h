@@ -51,7 +51,8 @@ enum llie_kind {
   LLIE_IRB = 1,    /* InvertedResidualBlock              efficient_unet.py:134-236 */
   LLIE_ATTN = 2,   /* LinearAttention                    efficient_unet.py:239-308 */
   LLIE_DOWN = 3,   /* Downsample (3x3 stride-2 conv)     efficient_unet.py:360-372 */
-  LLIE_UP = 4      /* Upsample (bilinear x2 + 3x3 conv)  efficient_unet.py:375-384 */
+  LLIE_UP = 4,     /* Upsample (bilinear x2 + 3x3 conv)  efficient_unet.py:375-384 */
+  LLIE_SE = 5      /* SqueezeExcitation (in_channels = C) efficient_unet.py:79-100; forward only */
 };
 
 /* Mirrors EfficientUNetConfig (efficient_unet.py:24-57) for LLIE_UNET; for the single-operator kinds
@@ -219,6 +220,7 @@ int llie_dwconv3x3_tiles(int H, int W);
  * `peak_measured` ("a copy-kernel bandwidth probe"; 2 x bytes move per call). */
 int llie_copy_probe(const void* src, void* dst, int64_t bytes, llie_stream stream);
 int llie_tune(const char* knob, int value); /* tuning knobs for tools/gpu_tune.py: "gemm_bk" = 0 (auto) | 32 */
+int llie_debug_irbx_stamps(double* out4); /* diagnostic builds: see irbx.hip (STAMP) */
 
 /* Per-kernel-class timing with HIP events recorded on the launch stream (what bench.py's `roofline`
  * object is computed from).  llie_profile_begin arms recording for the classes in `class_mask`;
@@ -240,6 +242,12 @@ int llie_profile_end(llie_ctx* ctx, int kernel_class, double* total_ms, int64_t*
 int llie_profile_report(llie_ctx* ctx, char* buf, size_t cap);
 /* Every recorded launch in launch order: lines "class\tkernel\toperator tag\tms\talgorithmic_bytes\n". */
 int llie_profile_dump(llie_ctx* ctx, char* buf, size_t cap);
+
+/* SinusoidalPosEmb + time_mlp of a LLIE_UNET handle on their own (efficient_unet.py:60-76, 412-417, and the SiLU
+ * that opens every block's FiLM projection, :189-192): emb [rows][base_channels] ([cos | sin]), temb [rows][T],
+ * silu_temb [rows][T]; timesteps device int64 [rows].  emb may be null. */
+int llie_time_embed(llie_ctx* ctx, const int64_t* timesteps, int rows, float* emb, float* temb, float* silu_temb,
+                    llie_stream stream);
 
 /* llie_algorithmic_bytes returns the roofline numerator of SURVEY.md 8d for one
  * UNet forward of `batch` images at the handle's dtype (activation traffic + weights once). */

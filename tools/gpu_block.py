@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""One InvertedResidualBlock shape in a loop (GPU box): the workload for rocprofv3 passes over a single kernel family, and
+the reader of the diagnostic in-kernel cycle stamps of expand_dw (llie_tune("irbx_stamp", 1)).
+usage: gpu_block.py [cin cout hw batch split reps irbx dbuf stamp]"""
+import ctypes as C
+import importlib
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+M = importlib.import_module("cv-diffusion-model_amd")
+N = importlib.import_module("cv-diffusion-model_amd._native")
+
+
+def main():
+    a = [int(v) for v in sys.argv[1:]]
+    cin, cout, hw, b, split, reps, irbx, dbuf, stamp = (a + [32, 32, 256, 32, 0, 10, 1, 1, 0][len(a):])[:9]
+    dev = torch.device("cuda:0")
+    L = N.lib()
+    N.check(L.llie_tune(b"irbx", irbx))
+    N.check(L.llie_tune(b"irbx_dbuf", dbuf))
+    N.check(L.llie_tune(b"irbx_stamp", stamp))
+    blk = M.InvertedResidualBlock(cin, cout, 128, concat_split=split).to(dev)
+    blk.compute_dtype = "fp16"
+    x = torch.rand(b, cin, hw, hw, device=dev) * 4 - 2
+    te = torch.rand(b, 128, device=dev) * 2 - 1
+    with torch.no_grad():
+        for _ in range(2):
+            blk(x, te)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            blk(x, te)
+        torch.cuda.synchronize()
+    print(f"irb {cin}->{cout} {hw}x{hw} B={b} irbx={irbx} dbuf={dbuf}: {(time.perf_counter() - t0) / reps * 1e3:.3f} ms per block "
+          f"(incl. NCHW<->NHWC conversion of the operator boundary)")
+    if stamp:
+        out = (C.c_double * 4)()
+        N.check(L.llie_debug_irbx_stamps(out))
+        tot = sum(out)
+        print("expand_dw mean cycles per wave (s_memtime, 100 MHz ticks x ...): "
+              + ", ".join(f"{n} {v:.0f} ({100 * v / tot:.0f}%)" for n, v in zip(["tile prologue", "MFMA phase", "barrier wait", "depthwise phase"], out)))
+
+
+if __name__ == "__main__":
+    main()
