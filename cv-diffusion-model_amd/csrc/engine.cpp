@@ -528,6 +528,7 @@ bool g_use_dwx = getenv("LLIE_DWX") != nullptr;
 // Recompute form, second generation (irbx.hip: statistics-only expand + tile-fused expand/depthwise): default for the
 // inference path of 2-byte engines wherever irbx_supported(); llie_tune("irbx", 0) restores the unfused pair.
 int g_use_irbx = getenv("LLIE_NO_IRBX") ? 0 : 1;
+int g_se_fused = 1;  // narrow blocks: the SE MLP in one launch (se_fused_kernel); llie_tune("se_fused", 0) = three-kernel chain
 // Backward pass: run the weight-gradient kernels on a side stream next to the activation-gradient chain
 // (llie_tune("bwd_async", 0) puts everything back on the caller's stream).
 int g_bwd_async = 1;
@@ -686,6 +687,7 @@ struct Run {
       e.w1 = wptr(w.se_w1); e.b1 = wptr<float>(w.se_b1); e.w2 = wptr(w.se_w2); e.b2 = wptr<float>(w.se_b2);
       e.mean = p<float>(semean); e.hid = p<float>(sehid); e.gate = p<float>(gate); e.B = B; e.C = w.hid; e.Cs = w.sq;
       timed(LLIE_K_SE, ((int64_t)B * dnt * w.hid * 4) + 2LL * w.hid * w.sq * (int64_t)es(), [&] {
+        if (g_se_fused && se_fused_supported(e)) return launch_se_fused(dt, e, s);
         hipError_t r1 = launch_se_fc1(dt, e, s);
         return r1 != hipSuccess ? r1 : launch_se_fc2(dt, e, s);
       });
@@ -2097,6 +2099,7 @@ int llie_tune(const char* knob, int value) {
   if (!strcmp(knob, "irbx_dbuf")) { irbx_tune(value, 0); return LLIE_OK; }
   if (!strcmp(knob, "irbx_tiles")) { irbx_tune(-1, value); return LLIE_OK; }
   if (!strcmp(knob, "irbx_stamp")) { irbx_stamp(value); return LLIE_OK; }
+  if (!strcmp(knob, "se_fused")) { g_se_fused = value; return LLIE_OK; }
   if (!strcmp(knob, "gemm_ablate")) { pw_gemm_debug(value); return LLIE_OK; }
   if (!strcmp(knob, "dw_ablate")) { dwconv_debug(value); return LLIE_OK; }
   if (!strcmp(knob, "dw_swap")) { dwconv_swap(value); return LLIE_OK; }

@@ -158,10 +158,10 @@ constexpr int kXH_W = kXT_W + 2, kXH_H = kXT_H + 2;  // halo tile 10 x 18 = 180 
 constexpr int kXNPX = kXH_W * kXH_H;
 constexpr int kXNPB = 6;
 
-// LDS image of the activated h1 tile: [pixel q][8 slots of 16 B = 64 channels], slot' = slot ^ (q & 3).
-// The 128-byte pixel pitch keeps the depthwise phase's ds_read_b128 conflict free (16-lane groups of gfx950);
-// the xor spreads the epilogue's ds_write_b128 (8 consecutive pixels, same slot) over 4 slots.
-__device__ __forceinline__ int xh_off(int q, int slot) { return q * 128 + ((slot ^ (q & 3)) << 4); }
+// LDS image of the activated h1 tile: [pixel q][64 channels + 16 B pad].  Both users address it with lane = pixel and a
+// fixed 16-byte channel slot (the expand epilogue's ds_write_b128, the depthwise MFMAs' ds_read_b128): the 144-byte
+// pitch (36 dwords) spreads consecutive pixels over distinct bank groups for either instruction's lane grouping.
+constexpr int SHP = 144;
 
 // STAMP = diagnostic build (llie_tune("irbx_stamp", 1)): s_memtime around the phases, summed per wave into a.dbg
 // ([workgroup][wave][4] = {tile prologue, MFMA phase, barrier wait, depthwise phase} cycles); never used in production.
@@ -171,7 +171,7 @@ __global__ void __launch_bounds__(256, 2) expand_dw_kernel(const IrbxArgs a, con
   constexpr int XP = (K + 8) * 2;                        // sX pixel pitch in bytes (80 / 144 / 208 / 272: conflict-free ds_read_b128)
   constexpr int XV = kXNPX * 2 * KS;                     // 16-byte vectors of one x halo tile
   constexpr int XPT = (XV + 255) / 256;                  // ... per thread
-  constexpr int SH_BYTES = kXNPB * 32 * 128;
+  constexpr int SH_BYTES = kXNPB * 32 * SHP;
   constexpr bool PREF = KS <= 2;                         // next tile's x prefetched into registers (36 VGPRs at KS = 6: not worth a spill)
   typedef typename Elem<T>::vec_t vec_t;
   extern __shared__ __align__(16) unsigned char smem[];
@@ -211,8 +211,21 @@ __global__ void __launch_bounds__(256, 2) expand_dw_kernel(const IrbxArgs a, con
   for (int i = tid; i < (kXNPB * 32 - kXNPX) * (XP / 16); i += 256)
     *reinterpret_cast<u32x4*>(sX + kXNPX * XP + i * 16) = u32x4{0u, 0u, 0u, 0u};
 
-  // depthwise phase roles
-  const int cl = tid & 7, xl = tid >> 3, cx = xl & 15, rh = xl >> 4;
+  // depthwise phase roles: wave = (channel block chb, output rows 4 pxg .. 4 pxg + 3); lane = pixel n of a 2-row block.
+  // dmask: where this lane's weight sits in the diagonal operand -- channel n of the block is element n & 7 of k-slice
+  // (n >> 3) = 2 s + h, i.e. one 16-bit half of one dword for one (s, h) and nothing elsewhere
+  uint32_t dmask[2][4];
+#pragma unroll
+  for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+      dmask[s2][d] = ((n >> 3) == 2 * s2 + h && ((n & 7) >> 1) == d) ? ((n & 1) ? 0xFFFF0000u : 0x0000FFFFu) : 0u;
+  int dq[2], drow[2];  // halo pixel of tap (0, 0) and output row of this lane in its two blocks
+#pragma unroll
+  for (int blk = 0; blk < 2; ++blk) {
+    drow[blk] = 2 * (2 * pxg + blk) + (n >> 4);
+    dq[blk] = drow[blk] * kXH_W + (n & 15);
+  }
 
   const int tile_first = blockIdx.x * tiles_per_wg;
   const int ntiles_img = tiles_x * (a.H / kXT_H);
@@ -259,8 +272,9 @@ __global__ void __launch_bounds__(256, 2) expand_dw_kernel(const IrbxArgs a, con
   int pend_tile = -1, pend_chunk = 0, pend_par = 0;  // pool partial waiting for its cross-wave sum
   auto flush_pool = [&]() {  // after a barrier that follows the depthwise phase which wrote red[pend_par]
     if (pend_tile >= 0 && tid < 64) {
-      const float* r = red + pend_par * 256;
-      const float t = r[tid] + r[64 + tid] + r[128 + tid] + r[192 + tid];
+      const float* r = red + pend_par * 256;  // wave (chb, pxg) = chb + 2 pxg left its 32 channel sums at [wave * 64 + channel]
+      const int cbb = tid >> 5, ci = tid & 31;
+      const float t = r[cbb * 64 + ci] + r[(cbb + 2) * 64 + ci];
       a.pool[((size_t)b * ntiles_img + pend_tile) * a.Chid + pend_chunk * 64 + tid] = t;
     }
     pend_tile = -1;
@@ -358,102 +372,100 @@ __global__ void __launch_bounds__(256, 2) expand_dw_kernel(const IrbxArgs a, con
           lo[j] = r02[0]; lo[2 + j] = r02[1];    // h=0: channels 0..7 of the block; h=1: channels 16..23
           hi2[j] = r13[0]; hi2[2 + j] = r13[1];  // h=0: channels 8..15;             h=1: channels 24..31
         }
-        *reinterpret_cast<u32x4*>(buf + xh_off(q, chb * 4 + 2 * h)) = lo;
-        *reinterpret_cast<u32x4*>(buf + xh_off(q, chb * 4 + 2 * h + 1)) = hi2;
+        *reinterpret_cast<u32x4*>(buf + q * SHP + (chb * 4 + 2 * h) * 16) = lo;
+        *reinterpret_cast<u32x4*>(buf + q * SHP + (chb * 4 + 2 * h + 1) * 16) = hi2;
       }
       stamp(1);
       __syncthreads();
       if (DBUF) flush_pool();
       stamp(2);
-      // ---- depthwise 3x3 on the LDS tile: thread = 8 channels x 4 output rows of one column
+      // ---- depthwise 3x3 on the MFMA pipe.  The VALU is what this kernel runs out of (a wave64 instruction costs a SIMD
+      // 4 cycles; 72 FMAs per 16 output bytes), the matrix pipe idles.  A depthwise tap is a diagonal matrix:
+      //   out[ch][px] += sum_k diag(w_tap)[ch][k] * in[k][px + tap]      (k over the block's channels, 16 per MFMA)
+      // so a wave owns 32 channels x two 32-pixel blocks (2 output rows each) and issues 9 taps x 2 k-steps x 2 blocks
+      // = 36 MFMAs: the data operand is one ds_read_b128 per MFMA (lane = pixel, 8 channels), the weight operand this
+      // lane's weight masked into its diagonal position (4 v_and per tap and k-step).  3 % of the MACs are useful, which
+      // still equals the VALU's rate -- on a pipe that was idle, for a quarter of the VALU instructions.
       {
-        const int c8 = chunk * 64 + cl * 8;
-        vec_t w[9];
+        const T* wcol = wds + chunk * 64 + chb * 32 + n;
+        f32x16 dacc[2];
 #pragma unroll
-        for (int t = 0; t < 9; ++t) w[t] = *reinterpret_cast<const vec_t*>(wds + t * a.Chid + c8);
-        float acc3[3][8], psum[8];
+        for (int r = 0; r < 16; ++r) dacc[0][r] = dacc[1][r] = 0.f;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) acc3[0][e] = acc3[1][e] = acc3[2][e] = psum[e] = 0.f;
-        T* orow = out + ((size_t)(y0 + rh * 4) * a.W + x0p + cx) * a.Chid + c8;
-        // rows are read one ahead of their use; the scheduling fences keep the compiler from hoisting all 18 reads
-        // (72 registers) in front of the arithmetic, which costs a wave of occupancy or spills
-        vec_t fn[3];
+        for (int tap = 0; tap < 9; ++tap) {
+          const int ky = tap / 3, kx = tap % 3;
+          const uint32_t wv = *reinterpret_cast<const uint16_t*>(wcol + tap * a.Chid);
+          const uint32_t wdup = wv | (wv << 16);
+          vec_t af[2];
 #pragma unroll
-        for (int kx = 0; kx < 3; ++kx) fn[kx] = *reinterpret_cast<const vec_t*>(buf + xh_off((rh * 4) * kXH_W + cx + kx, cl));
+          for (int s2 = 0; s2 < 2; ++s2) {
+            u32x4 t;
 #pragma unroll
-        for (int r = 0; r < 6; ++r) {  // halo rows rh*4 + r
-          vec_t f[3];
-#pragma unroll
-          for (int kx = 0; kx < 3; ++kx) f[kx] = fn[kx];
-          if (r < 5) {
-            const int qrow = (rh * 4 + r + 1) * kXH_W + cx;
-#pragma unroll
-            for (int kx = 0; kx < 3; ++kx) fn[kx] = *reinterpret_cast<const vec_t*>(buf + xh_off(qrow + kx, cl));
+            for (int d = 0; d < 4; ++d) t[d] = wdup & dmask[s2][d];
+            af[s2] = reinterpret_cast<const vec_t&>(t);
           }
-          __builtin_amdgcn_sched_barrier(0);
-          float* a2 = acc3[(r + 1) % 3];  // ky = 2 -> output row r-2
-          float* a1 = acc3[(r + 2) % 3];  // ky = 1 -> output row r-1
-          float* a0 = acc3[r % 3];        // ky = 0 -> output row r
-          if constexpr (std::is_same<T, half_t>::value) {
 #pragma unroll
-            for (int kx = 0; kx < 3; ++kx) {
-              const u32x4 fq = reinterpret_cast<const u32x4&>(f[kx]);
-              const u32x4 w2 = reinterpret_cast<const u32x4&>(w[6 + kx]);
-              const u32x4 w1v = reinterpret_cast<const u32x4&>(w[3 + kx]);
-              const u32x4 w0 = reinterpret_cast<const u32x4&>(w[0 + kx]);
+          for (int blk = 0; blk < 2; ++blk) {
+            const int q = dq[blk] + ky * kXH_W + kx;
 #pragma unroll
-              for (int q4 = 0; q4 < 4; ++q4) {
-                if (r >= 2) { fma_mix_lo(a2[2 * q4], w2[q4], fq[q4]); fma_mix_hi(a2[2 * q4 + 1], w2[q4], fq[q4]); }
-                if (r >= 1 && r <= 4) { fma_mix_lo(a1[2 * q4], w1v[q4], fq[q4]); fma_mix_hi(a1[2 * q4 + 1], w1v[q4], fq[q4]); }
-                if (r <= 3) { fma_mix_lo(a0[2 * q4], w0[q4], fq[q4]); fma_mix_hi(a0[2 * q4 + 1], w0[q4], fq[q4]); }
-              }
-            }
-          } else {
-            // bf16 has no mixed-precision FMA; v_dot2c_f32_bf16 on a data word with one half masked off is one: weights stay
-            // packed, no conversions (acc += w.lo * f.lo + w.hi * 0)
-#pragma unroll
-            for (int kx = 0; kx < 3; ++kx) {
-              const u32x4 fq = reinterpret_cast<const u32x4&>(f[kx]);
-              const u32x4 w2 = reinterpret_cast<const u32x4&>(w[6 + kx]);
-              const u32x4 w1v = reinterpret_cast<const u32x4&>(w[3 + kx]);
-              const u32x4 w0 = reinterpret_cast<const u32x4&>(w[0 + kx]);
-#pragma unroll
-              for (int q4 = 0; q4 < 4; ++q4) {
-                const uint32_t flo = fq[q4] & 0x0000FFFFu, fhi = fq[q4] & 0xFFFF0000u;
-                if (r >= 2) { a2[2 * q4] = dot2_bf16(w2[q4], flo, a2[2 * q4]); a2[2 * q4 + 1] = dot2_bf16(w2[q4], fhi, a2[2 * q4 + 1]); }
-                if (r >= 1 && r <= 4) { a1[2 * q4] = dot2_bf16(w1v[q4], flo, a1[2 * q4]); a1[2 * q4 + 1] = dot2_bf16(w1v[q4], fhi, a1[2 * q4 + 1]); }
-                if (r <= 3) { a0[2 * q4] = dot2_bf16(w0[q4], flo, a0[2 * q4]); a0[2 * q4 + 1] = dot2_bf16(w0[q4], fhi, a0[2 * q4 + 1]); }
-              }
-            }
+            for (int s2 = 0; s2 < 2; ++s2)
+              dacc[blk] = mfma16<T>(af[s2], *reinterpret_cast<const vec_t*>(buf + q * SHP + (chb * 4 + 2 * s2 + h) * 16), dacc[blk]);
           }
-          if (r >= 2) {
-            vec_t ov = f32_to_vec<T>(a2);
-            st_vec<T>(orow + (size_t)(r - 2) * a.W * a.Chid, ov);
-            if constexpr (std::is_same<T, half_t>::value) {
-              const u32x4 oq = reinterpret_cast<const u32x4&>(ov);
-#pragma unroll
-              for (int q4 = 0; q4 < 4; ++q4) {  // psum += 1.0h * ov: the rounded value, one instruction per element
-                fma_mix_lo(psum[2 * q4], 0x3C003C00u, oq[q4]);
-                fma_mix_hi(psum[2 * q4 + 1], 0x3C003C00u, oq[q4]);
-              }
-#pragma unroll
-              for (int e = 0; e < 8; ++e) a2[e] = 0.f;
-            } else {
-              const u32x4 oq = reinterpret_cast<const u32x4&>(ov);
-#pragma unroll
-              for (int q4 = 0; q4 < 4; ++q4) {  // psum += 1.0 * ov (0x3F80 = bf16 one)
-                psum[2 * q4] = dot2_bf16(0x3F803F80u, oq[q4] & 0x0000FFFFu, psum[2 * q4]);
-                psum[2 * q4 + 1] = dot2_bf16(0x3F803F80u, oq[q4] & 0xFFFF0000u, psum[2 * q4 + 1]);
-              }
-#pragma unroll
-              for (int e = 0; e < 8; ++e) a2[e] = 0.f;
-            }
-          }
-          __builtin_amdgcn_sched_barrier(0);
         }
-        // SE pool partial of this (tile, chunk): lanes -> per-wave channel sums -> red[par][wave][64]
+        // accumulators: lane = pixel n of the block, 16 channels (r&3) + 8(r>>2) + 4h -> T, lane halves exchanged so that
+        // each lane owns 8 consecutive channels, two 16-byte stores per block
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) {
+          uint32_t pk[4][2];
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            typedef T t2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+              t2 o;
+              o[0] = (T)dacc[blk][4 * g + 2 * j];
+              o[1] = (T)dacc[blk][4 * g + 2 * j + 1];
+              pk[g][j] = *reinterpret_cast<uint32_t*>(&o);
+            }
+          }
+          u32x4 lo, hi2;
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            const u32x2 r02 = __builtin_amdgcn_permlane32_swap(pk[0][j], pk[2][j], false, false);
+            const u32x2 r13 = __builtin_amdgcn_permlane32_swap(pk[1][j], pk[3][j], false, false);
+            lo[j] = r02[0]; lo[2 + j] = r02[1];
+            hi2[j] = r13[0]; hi2[2 + j] = r13[1];
+          }
+          T* op = out + ((size_t)(y0 + drow[blk]) * a.W + x0p + (n & 15)) * a.Chid + chunk * 64 + chb * 32 + 16 * h;
+          *reinterpret_cast<u32x4*>(op) = lo;
+          *reinterpret_cast<u32x4*>(op + 8) = hi2;
+        }
+        // SE pool partial of this (tile, chunk): the 16 channel values of a lane summed over the wave's 64 pixels -- the
+        // two blocks in registers, then a halving butterfly over the 32 pixel lanes (lane n ends up with channel slot (n>>1)&15)
         if (a.pool) {
-          pool_segment_flush<8>(psum, red + (DBUF ? par : 0) * 256 + wave * 64, lane);
+          float v[16];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) v[r] = dacc[0][r] + dacc[1][r];
+#pragma unroll
+          for (int lvl = 0; lvl < 4; ++lvl) {
+            const int bit = 16 >> lvl, half = 8 >> lvl;
+            // lane-dependent choice between two registers as a bit blend with an opaque all-ones / zero mask (v_bfi_b32):
+            // written as `up ? v[half + i] : v[i]` the compiler turns the four levels into a 16-way indexed select chain
+            uint32_t m = (n & bit) ? 0xFFFFFFFFu : 0u;
+            asm volatile("" : "+v"(m));
+#pragma unroll
+            for (int i = 0; i < half; ++i) {
+              const uint32_t lo = __float_as_uint(v[i]), hi = __float_as_uint(v[half + i]);
+              const float keep = __uint_as_float((hi & m) | (lo & ~m));
+              const float send = __uint_as_float((lo & m) | (hi & ~m));
+              v[i] = keep + __shfl_xor(send, bit, 64);
+            }
+          }
+          v[0] += __shfl_xor(v[0], 1, 64);
+          if ((n & 1) == 0) {
+            const int r = (n >> 1) & 15;
+            red[(DBUF ? par : 0) * 256 + wave * 64 + (r & 3) + 8 * (r >> 2) + 4 * h] = v[0];
+          }
           pend_tile = tile; pend_chunk = chunk; pend_par = DBUF ? par : 0;
         }
       }
@@ -535,7 +547,7 @@ hipError_t launch_expand_stats(int dtype, const IrbxArgs& a, hipStream_t s) {
 
 template <typename T, int KS, bool DBUF>
 static hipError_t launch_dw_cfg(const IrbxArgs& a, hipStream_t s) {
-  const size_t lds = (size_t)(DBUF ? 2 : 1) * kXNPB * 32 * 128 + (size_t)kXNPB * 32 * (16 * KS + 8) * 2 + (size_t)9 * a.Chid * 2 +
+  const size_t lds = (size_t)(DBUF ? 2 : 1) * kXNPB * 32 * SHP + (size_t)kXNPB * 32 * (16 * KS + 8) * 2 + (size_t)9 * a.Chid * 2 +
                      (size_t)2 * a.Chid * 4 + (size_t)2 * 16 * KS * 4 + 2 * 256 * 4;
   static bool attr_done = false;
   if (!attr_done) {

@@ -148,6 +148,8 @@ struct SeArgs {
   float* gate;                      // [B][C]
   int B, C, Cs;
 };
+bool se_fused_supported(const SeArgs& a);   // one-launch form for narrow blocks (se_fused_kernel)
+hipError_t launch_se_fused(int dtype, const SeArgs& a, hipStream_t s);
 hipError_t launch_se_fc1(int dtype, const SeArgs& a, hipStream_t s);
 hipError_t launch_se_fc2(int dtype, const SeArgs& a, hipStream_t s);
 
