@@ -375,7 +375,7 @@ ALL_CLASSES = 31
 def kernel_class_of(name: str, native) -> int:
     if name.startswith(("pw_gemm", "expand_stats")):
         return native.K_GEMM
-    if name.startswith(("dwconv3x3", "expand_dw", "dwx_kernel")):
+    if name.startswith(("dwconv3x3", "expand_dw")):
         return native.K_DW
     if name.startswith("conv3x3"):
         return native.K_CONV3

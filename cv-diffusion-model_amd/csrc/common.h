@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "kernels.h"
 
 namespace llie {
@@ -80,6 +82,45 @@ __device__ __forceinline__ void fma_mix_lo(float& acc, uint32_t w2, uint32_t f2)
 }
 __device__ __forceinline__ void fma_mix_hi(float& acc, uint32_t w2, uint32_t f2) {
   asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,1,0]" : "+v"(acc) : "v"(w2), "v"(f2));
+}
+
+// ---------------------------------------------------------------------------------------------
+// Packed affine (+ clamp to [0, 1]) for operand prologues.  The kernels of this engine run out of VALU issue slots
+// before anything else (a wave64 instruction holds its SIMD for 4 cycles), so ReLU6 is carried as clamp01(z / 6) -- the
+// clamp is the FMA's free output modifier -- and the factor 6 is pushed through the linear operator that follows.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+constexpr float kSixth = 1.f / 6.f;
+__device__ __forceinline__ float clamp01f(float x) { return __builtin_amdgcn_fmed3f(x, 0.f, 1.f); }
+
+// one packed dword of T: { [clamp01](a0 * s0 + b0), [clamp01](a1 * s1 + b1) }, all inputs fp32.  Plain C on purpose: callers
+// feed it MFMA results, and hipcc pads the MFMA -> VALU read hazard only for instructions it emits itself (an asm
+// consumer reads stale accumulators); it folds the med3 into the FMA's clamp bit (v_fma_f32 ... clamp + v_cvt_pk).
+template <typename T, bool CLAMP = true>
+__device__ __forceinline__ uint32_t affine_clamp01_pack(float a0, float a1, float s0, float s1, float b0, float b1) {
+  typedef T t2 __attribute__((ext_vector_type(2)));
+  t2 o;
+  const float v0 = __builtin_fmaf(a0, s0, b0), v1 = __builtin_fmaf(a1, s1, b1);
+  o[0] = (T)(CLAMP ? clamp01f(v0) : v0);
+  o[1] = (T)(CLAMP ? clamp01f(v1) : v1);
+  return *reinterpret_cast<uint32_t*>(&o);
+}
+// the same with the two inputs taken from a packed dword of T (loaded data, never an MFMA result): for f16 one
+// v_fma_mixlo/hi_f16 per value, rounded once
+template <typename T, bool CLAMP = true>
+__device__ __forceinline__ uint32_t act_clamp01_pack(uint32_t x2, float s0, float s1, float b0, float b1) {
+  if constexpr (std::is_same<T, half_t>::value) {
+    uint32_t r;
+    if constexpr (CLAMP) {
+      asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0] clamp" : "=v"(r) : "v"(x2), "v"(s0), "v"(b0));
+      asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0] clamp" : "+v"(r) : "v"(x2), "v"(s1), "v"(b1));
+    } else {
+      asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(x2), "v"(s0), "v"(b0));
+      asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(r) : "v"(x2), "v"(s1), "v"(b1));
+    }
+    return r;
+  } else {
+    return affine_clamp01_pack<T, CLAMP>(__uint_as_float(x2 << 16), __uint_as_float(x2 & 0xFFFF0000u), s0, s1, b0, b1);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -37,7 +37,7 @@ constexpr int kDwPF = 4;  // rows of global loads kept in flight per thread
 // multiplies each output by the ReLU6 derivative of the forward pre-activation z = bx*bas + bab (bx = the tensor the
 // forward depthwise read) and writes per-8-row-segment partial sums (sum dz, sum dz*bx) for the GroupNorm backward,
 // in place of the SE pool partials.  The forward instantiation (BWD = false) compiles none of it.
-template <typename T, int TX, int PFV, bool BWD>
+template <typename T, int TX, int PFV, bool BWD, bool S6 = false>
 __device__ __forceinline__ void dw_body(const DwArgs& a, const int TYL, const int dbg, const int swap) {
   constexpr int NT = 8 * TX;
   constexpr int VEC = Elem<T>::VEC;
@@ -76,7 +76,7 @@ __device__ __forceinline__ void dw_body(const DwArgs& a, const int TYL, const in
 #pragma unroll
   for (int t = 0; t < 9; ++t)
 #pragma unroll
-    for (int e = 0; e < VEC; ++e) w[t][e] = (T)a.w[(size_t)t * a.C + c0 + e];
+    for (int e = 0; e < VEC; ++e) w[t][e] = (T)((S6 ? 6.f : 1.f) * a.w[(size_t)t * a.C + c0 + e]);
 
   const int nrows = TYL + 2;  // input rows y0-1 .. y0+TYL
   vec_t pre[PF], preh[PF];
@@ -89,6 +89,13 @@ __device__ __forceinline__ void dw_body(const DwArgs& a, const int TYL, const in
     }
   };
   auto activate = [&](vec_t v) {
+    if constexpr (S6 && sizeof(T) == 2) {  // relu6(z) / 6 = clamp01(z / 6): one FMA per value, the clamp is free
+      const u32x4 x = reinterpret_cast<const u32x4&>(v);
+      u32x4 o;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) o[q] = act_clamp01_pack<T, true>(x[q], sc[2 * q], sc[2 * q + 1], sh[2 * q], sh[2 * q + 1]);
+      return reinterpret_cast<const vec_t&>(o);
+    }
     float f[VEC];
     vec_to_f32<T>(v, f);
 #pragma unroll
@@ -232,10 +239,10 @@ __device__ __forceinline__ void dw_body(const DwArgs& a, const int TYL, const in
   }
 }
 
-template <typename T, int TX, int PFV>
+template <typename T, int TX, int PFV, bool S6 = false>
 __global__ void __launch_bounds__(8 * TX, (std::is_same<T, bf16_t>::value ? 3 : 1))
 dwconv3x3_kernel(const DwArgs a, const int TYL, const int dbg, const int swap) {
-  dw_body<T, TX, PFV, false>(a, TYL, dbg, swap);
+  dw_body<T, TX, PFV, false, S6>(a, TYL, dbg, swap);
 }
 template <typename T, int TX, int PFV>
 __global__ void __launch_bounds__(8 * TX) dwconv3x3_bwd_kernel(const DwArgs a, const int TYL, const int swap) {
@@ -276,6 +283,17 @@ static hipError_t launch_dw_t(const DwArgs& a, hipStream_t s) {
     else if (tx == 16) hipLaunchKernelGGL((dwconv3x3_bwd_kernel<T, 16, kDwPF>), grid, dim3(128), 0, s, a, tyl, g_dw_swap);
     else hipLaunchKernelGGL((dwconv3x3_bwd_kernel<T, 8, kDwPF>), grid, dim3(64), 0, s, a, tyl, g_dw_swap);
     return hipGetLastError();
+  }
+  if constexpr (sizeof(T) == 2) {
+    if (a.s6) {
+      if (a.no_act) return hipErrorInvalidValue;
+      if (tx == 32) hipLaunchKernelGGL((dwconv3x3_kernel<T, 32, kDwPF, true>), grid, dim3(256), 0, s, a, tyl, g_dw_dbg & 3, g_dw_swap);
+      else if (tx == 16) hipLaunchKernelGGL((dwconv3x3_kernel<T, 16, kDwPF, true>), grid, dim3(128), 0, s, a, tyl, g_dw_dbg & 3, g_dw_swap);
+      else hipLaunchKernelGGL((dwconv3x3_kernel<T, 8, kDwPF, true>), grid, dim3(64), 0, s, a, tyl, g_dw_dbg & 3, g_dw_swap);
+      return hipGetLastError();
+    }
+  } else if (a.s6) {
+    return hipErrorInvalidValue;
   }
   if (tx == 32) hipLaunchKernelGGL((dwconv3x3_kernel<T, 32, kDwPF>), grid, dim3(256), 0, s, a, tyl, g_dw_dbg & 3, g_dw_swap);
   else if (tx == 16) hipLaunchKernelGGL((dwconv3x3_kernel<T, 16, kDwPF>), grid, dim3(128), 0, s, a, tyl, g_dw_dbg & 3, g_dw_swap);

@@ -520,12 +520,7 @@ int build_module(llie_ctx* c) {
 
 // ---------------------------------------------------------------------------------------------
 // Run helpers.  In dry mode nothing is launched; only the arena is exercised.
-// Fused expand+depthwise ("recompute" form, dwx.hip) for 2-byte dtypes.  Numerically equivalent, but as
-// built it is slower than the unfused pair on MI355X (6.2 vs 3.6 ms/forward for the depthwise class at
-// small@256 B=32 fp16; K1 without stores only drops 5.0 -> 4.6 ms), so it is opt-in: LLIE_DWX=1 or
-// llie_tune("dwx", 1).  See DESIGN.md section 8.
-bool g_use_dwx = getenv("LLIE_DWX") != nullptr;
-// Recompute form, second generation (irbx.hip: statistics-only expand + tile-fused expand/depthwise): default for the
+// Recompute form (irbx.hip: statistics-only expand + tile-fused expand/depthwise): default for the
 // inference path of 2-byte engines wherever irbx_supported(); llie_tune("irbx", 0) restores the unfused pair.
 int g_use_irbx = getenv("LLIE_NO_IRBX") ? 0 : 1;
 int g_se_fused = 1;  // narrow blocks: the SE MLP in one launch (se_fused_kernel); llie_tune("se_fused", 0) = three-kernel chain
@@ -589,7 +584,7 @@ struct Run {
 
   // GroupNorm affine of (x0 [+ x1]) -> freshly allocated as/ab [B][C]; returns offsets
   void gn(const Tens& x0, const Tens* x1, size_t gamma, size_t beta, const float* film, int64_t film_stride,
-          size_t& as, size_t& ab, GnRec* rec = nullptr) {
+          size_t& as, size_t& ab, GnRec* rec = nullptr, float post_scale = 0.f) {
     const int C = x0.C + (x1 ? x1->C : 0);
     const int Creal = x0.Cr + (x1 ? x1->Cr : 0);  // x0 is unpadded whenever x1 exists (checked at build time)
     as = ar->alloc((size_t)B * C * 4);
@@ -607,7 +602,7 @@ struct Run {
     a.C = C; a.Creal = Creal; a.groups = gn_groups(Creal); a.P = x0.H * x0.W;
     a.gamma = wptr<float>(gamma); a.beta = wptr<float>(beta);
     a.film = film; a.film_stride = film_stride; a.eps = 1e-5f;
-    a.as = p<float>(as); a.ab = p<float>(ab); a.B = B;
+    a.as = p<float>(as); a.ab = p<float>(ab); a.B = B; a.post_scale = post_scale;
     if (tape && rec) { a.mean_out = p<float>(mo); a.rstd_out = p<float>(ro); }
     timed(LLIE_K_OTHER, (int64_t)B * C * 8, [&] { return launch_gn_finalize(a, s); }, "gn_finalize_kernel");
   }
@@ -619,16 +614,18 @@ struct Run {
     size_t as1, ab1;
     IrbRec rec{};
     snprintf(tag, sizeof tag, "irb P=%d %d->%d hid=%d", P, w.cin, w.cout, w.hid);
-    gn(x0, x1, w.n1g, w.n1b, nullptr, 0, as1, ab1, &rec.n1);
-    // Recompute form (2-byte T, narrow inputs): K1 only produces h1's statistics and the fused
-    // expand+depthwise kernel rebuilds h1 on the fly, so the 4x-expanded tensor never touches HBM.
+    // 2-byte inference engines carry norm1's ReLU6 as clamp01(z / 6): the tables come out divided by 6 and the expand
+    // GEMM (or the recompute kernels) puts the 6 back (kernels.h: ACT_RELU6_S6).  Training keeps the plain tables.
+    const bool s6 = !tape && dt != LLIE_F32;
+    gn(x0, x1, w.n1g, w.n1b, nullptr, 0, as1, ab1, &rec.n1, s6 ? 1.f / 6.f : 0.f);
+    // Recompute form (2-byte T, narrow inputs): a statistics-only expand pass, then the fused expand + depthwise kernel
+    // rebuilds h1 on the fly, so the 4x-expanded tensor never touches HBM (irbx.hip).
     const bool fusedx = !tape && g_use_irbx && w.hid == w.hid_r && w.cin == w.cin_r &&
                         irbx_supported(dt, w.cin, x0.C, w.hid, H, W);
-    const bool fused = !fusedx && !tape && g_use_dwx && dwx_supported(dt, w.cin, w.hid, H, W);
     // K1: expand with norm1 + ReLU6 prologue
     Tens h1;
     h1.C = w.hid; h1.Cr = w.hid_r; h1.H = H; h1.W = W; h1.ntiles = fusedx ? P / irbx_stats_rows(P) : P / BM; h1.valid = true;
-    h1.off = (fused || fusedx) ? 0 : ar->alloc((size_t)B * P * w.hid * es());
+    h1.off = fusedx ? 0 : ar->alloc((size_t)B * P * w.hid * es());
     h1.slab = ar->alloc((size_t)B * h1.ntiles * 2 * w.hid * 4);
     IrbxArgs xa{};
     if (fusedx && !dry) {
@@ -638,20 +635,24 @@ struct Run {
       timed(LLIE_K_GEMM, ((int64_t)M * w.cin + (int64_t)w.hid * w.cin) * (int64_t)es(), [&] { return launch_expand_stats(dt, xa, s); });
     } else if (!dry) {
       GemmArgs g{};
-      g.seg[0] = GemmSeg{p(x0.off), x0.C, p<float>(as1), p<float>(ab1), w.cin, ACT_RELU6};
+      const int act1 = s6 ? ACT_RELU6_S6 : ACT_RELU6;
+      g.seg[0] = GemmSeg{p(x0.off), x0.C, p<float>(as1), p<float>(ab1), w.cin, act1};
       g.nseg = 1;
       if (x1) {
-        g.seg[1] = GemmSeg{p(x1->off), x1->C, p<float>(as1) + x0.C, p<float>(ab1) + x0.C, w.cin, ACT_RELU6};
+        g.seg[1] = GemmSeg{p(x1->off), x1->C, p<float>(as1) + x0.C, p<float>(ab1) + x0.C, w.cin, act1};
         g.nseg = 2;
       }
-      g.w = wptr(w.w_expand); g.out = fused ? nullptr : p(h1.off); g.stats = p<float>(h1.slab);
-      g.M = M; g.N = w.hid; g.K = w.cin; g.P = P; g.nostore = fused ? 1 : 0;
-      timed(LLIE_K_GEMM, ((int64_t)M * (w.cin + (fused ? 0 : w.hid)) + (int64_t)w.hid * w.cin) * (int64_t)es(),
+      g.w = wptr(w.w_expand); g.out = p(h1.off); g.stats = p<float>(h1.slab);
+      g.M = M; g.N = w.hid; g.K = w.cin; g.P = P;
+      timed(LLIE_K_GEMM, ((int64_t)M * (w.cin + w.hid) + (int64_t)w.hid * w.cin) * (int64_t)es(),
             [&] { return launch_pw_gemm(dt, g, s); });
     }
     // norm2 + FiLM folded into one affine
     size_t as2, ab2;
-    gn(h1, nullptr, w.n2g, w.n2b, film ? film + w.film_off : nullptr, film_stride, as2, ab2, &rec.n2);
+    // unfused depthwise of a 2-byte inference engine: tables / 6 and clamp01 in its prologue too (DwArgs::s6); the
+    // recompute kernel takes the plain tables (it rescales the shift itself: its accumulators are already / 6)
+    const bool s6dw = s6 && !fusedx;
+    gn(h1, nullptr, w.n2g, w.n2b, film ? film + w.film_off : nullptr, film_stride, as2, ab2, &rec.n2, s6dw ? 1.f / 6.f : 0.f);
     // K2: depthwise with affine + ReLU6 prologue and SE pool partials
     const int dnt = fusedx ? irbx_pool_tiles(H, W) : dwconv_ntiles(H, W);
     const size_t h2 = ar->alloc((size_t)M * w.hid * es());
@@ -660,22 +661,15 @@ struct Run {
       if (fusedx) {
         xa.as2 = p<float>(as2); xa.ab2 = p<float>(ab2); xa.out = p(h2); xa.pool = p<float>(pool);
         timed(LLIE_K_DW, (int64_t)M * (w.cin + w.hid) * (int64_t)es(), [&] { return launch_expand_dw(dt, xa, s); });
-      } else if (fused) {
-        DwxArgs d{};
-        d.x0 = p(x0.off); d.c0 = x0.C; d.x1 = x1 ? p(x1->off) : nullptr; d.c1 = x1 ? x1->C : 0;
-        d.as1 = p<float>(as1); d.ab1 = p<float>(ab1); d.w1 = wptr(w.w_expand);
-        d.as2 = p<float>(as2); d.ab2 = p<float>(ab2); d.wd = wptr<float>(w.w_dw);
-        d.out = p(h2); d.pool = p<float>(pool); d.B = B; d.H = H; d.W = W; d.Chid = w.hid;
-        timed(LLIE_K_DW, (int64_t)M * (w.cin + w.hid) * (int64_t)es(), [&] { return launch_dwx(dt, d, s); });
       } else {
         DwArgs d{};
         d.in = p(h1.off); d.out = p(h2); d.as = p<float>(as2); d.ab = p<float>(ab2);
-        d.w = wptr<float>(w.w_dw); d.pool = p<float>(pool); d.B = B; d.H = H; d.W = W; d.C = w.hid;
+        d.w = wptr<float>(w.w_dw); d.pool = p<float>(pool); d.B = B; d.H = H; d.W = W; d.C = w.hid; d.s6 = s6dw ? 1 : 0;
         timed(LLIE_K_DW, 2LL * M * w.hid * (int64_t)es(), [&] { return launch_dwconv3x3(dt, d, s); });
       }
     }
     rel(as1); rel(ab1);
-    if (!fused && !fusedx) rel(h1.off);
+    if (!fusedx) rel(h1.off);
     rel(h1.slab);
     rel(as2); rel(ab2);
     // SE MLP
@@ -2093,12 +2087,11 @@ int llie_tune(const char* knob, int value) {
   if (!knob) return LLIE_ERR_ARG;
   ++g_tune_epoch;
   if (!strcmp(knob, "gemm_bk")) { pw_gemm_force_bk(value); return LLIE_OK; }
-  if (!strcmp(knob, "gemm_v2")) { pw_gemm_use_v2(value); return LLIE_OK; }
-  if (!strcmp(knob, "dwx")) { g_use_dwx = value != 0; return LLIE_OK; }
   if (!strcmp(knob, "irbx")) { g_use_irbx = value != 0; return LLIE_OK; }
   if (!strcmp(knob, "irbx_dbuf")) { irbx_tune(value, 0); return LLIE_OK; }
   if (!strcmp(knob, "irbx_tiles")) { irbx_tune(-1, value); return LLIE_OK; }
   if (!strcmp(knob, "irbx_stamp")) { irbx_stamp(value); return LLIE_OK; }
+  if (!strcmp(knob, "irbx_ablate")) { irbx_ablate(value); return LLIE_OK; }
   if (!strcmp(knob, "se_fused")) { g_se_fused = value; return LLIE_OK; }
   if (!strcmp(knob, "gemm_ablate")) { pw_gemm_debug(value); return LLIE_OK; }
   if (!strcmp(knob, "dw_ablate")) { dwconv_debug(value); return LLIE_OK; }

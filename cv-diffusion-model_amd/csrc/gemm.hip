@@ -104,14 +104,37 @@ __global__ void __launch_bounds__(WM* WN * 64) pw_gemm_kernel(const GemmArgs g) 
         const int row = idx / VPR;
         vec_t v = ra[i];
         if (r_aff) {
-          float f[VEC];
-          vec_to_f32<T>(v, f);
+          if constexpr (sizeof(T) == 2) {
+            // 2-byte T: one FMA per value straight from the packed word (f16: v_fma_mixlo/hi_f16), ReLU6 as the free clamp
+            // of clamp01(z / 6) when the tables come pre-divided (ACT_RELU6_S6).  This prologue is redone for every N tile,
+            // and the kernel is short of VALU issue slots before it is short of anything else.
+            if (r_act != ACT_RELU6) {
+              u32x4 x = reinterpret_cast<const u32x4&>(v), o;
+              if (r_act == ACT_RELU6_S6) {
 #pragma unroll
-          for (int e = 0; e < VEC; ++e) {
-            float x = f[e] * rs[e] + rbv[e];
-            f[e] = r_act == ACT_RELU6 ? relu6f(x) : x;
+                for (int q = 0; q < 4; ++q) o[q] = act_clamp01_pack<T, true>(x[q], rs[2 * q], rs[2 * q + 1], rbv[2 * q], rbv[2 * q + 1]);
+              } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) o[q] = act_clamp01_pack<T, false>(x[q], rs[2 * q], rs[2 * q + 1], rbv[2 * q], rbv[2 * q + 1]);
+              }
+              v = reinterpret_cast<const vec_t&>(o);
+            } else {
+              float f[VEC];
+              vec_to_f32<T>(v, f);
+#pragma unroll
+              for (int e = 0; e < VEC; ++e) f[e] = relu6f(f[e] * rs[e] + rbv[e]);
+              v = f32_to_vec<T>(f);
+            }
+          } else {
+            float f[VEC];
+            vec_to_f32<T>(v, f);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+              float x = f[e] * rs[e] + rbv[e];
+              f[e] = r_act == ACT_RELU6 ? relu6f(x) : x;
+            }
+            v = f32_to_vec<T>(f);
           }
-          v = f32_to_vec<T>(f);
         }
         st_vec<T>(sA + row * PITCH + kv, v);
       }
@@ -168,6 +191,7 @@ __global__ void __launch_bounds__(WM* WN * 64) pw_gemm_kernel(const GemmArgs g) 
   static_assert(NT % VR == 0 && VR <= 64, "epilogue mapping");
   static_assert(SG == 1 || (RPP <= 32 && 32 % RPP == 0 && MI * 32 == G), "per-group statistics need one wave row per group");
   const int cv = tid % VR, r0 = tid / VR;
+  const float oscale = g.seg[0].act == ACT_RELU6_S6 ? 6.f : 1.f;  // the operand was relu6(.) / 6
   float bias[VEC], s1[SG][VEC], s2[SG][VEC];
 #pragma unroll
   for (int e = 0; e < VEC; ++e) {
@@ -199,7 +223,7 @@ __global__ void __launch_bounds__(WM* WN * 64) pw_gemm_kernel(const GemmArgs g) 
       float v[VEC];
       const float* pc = sC + srow * CP + cv * VEC;
 #pragma unroll
-      for (int e = 0; e < VEC; ++e) v[e] = pc[e] + bias[e];
+      for (int e = 0; e < VEC; ++e) v[e] = pc[e] * oscale + bias[e];
       const size_t o = (size_t)(m0 + row) * g.N + n0 + cv * VEC;
       if (resp) {
         float rr[VEC];
@@ -311,11 +335,8 @@ static hipError_t launch_t(const GemmArgs& a, hipStream_t s) {
   return launch_cfg<T, 64, 32, 2, 1, 32>(a, s);
 }
 
-// g_gemm_v2: the LDS-DMA pipelined variant (gemm2.hip) is numerically equivalent but measured 1.4x slower on
-// MI355X over the layer shapes of small@256, so it is opt-in: llie_tune("gemm_v2", 1).
-static int g_gemm_dbg = 0, g_gemm_v2 = 0;
+static int g_gemm_dbg = 0;
 void pw_gemm_debug(int v) { g_gemm_dbg = v; }
-void pw_gemm_use_v2(int v) { g_gemm_v2 = v; }
 
 hipError_t launch_pw_gemm(int dtype, const GemmArgs& a0, hipStream_t s) {
   GemmArgs a = a0;
@@ -330,7 +351,9 @@ hipError_t launch_pw_gemm(int dtype, const GemmArgs& a0, hipStream_t s) {
     k += a.seg[i].ch;
   }
   if (k != a.K) return hipErrorInvalidValue;
-  if (g_gemm_v2 && !a.dbg && pw_gemm2_supported(dtype, a)) return launch_pw_gemm2(a, s);
+  for (int i = 0; i < a.nseg; ++i)  // the output scale of ACT_RELU6_S6 is per GEMM: all segments or none, 2-byte T only
+    if ((a.seg[i].act == ACT_RELU6_S6) != (a.seg[0].act == ACT_RELU6_S6) || (a.seg[i].act == ACT_RELU6_S6 && (dtype == 0 || !a.seg[i].as)))
+      return hipErrorInvalidValue;
   switch (dtype) {
     case 0: return launch_t<float>(a, s);
     case 1: return launch_t<half_t>(a, s);

@@ -39,20 +39,25 @@ __device__ __forceinline__ float dot2_bf16(uint32_t a, uint32_t b, float c) {
   return __builtin_amdgcn_fdot2_f32_bf16(*reinterpret_cast<const bf16x2_t*>(&a), *reinterpret_cast<const bf16x2_t*>(&b), c, false);
 }
 
-// a' = relu6(a * s + b) on one 16-byte operand slice (8 channels); sc / sh point at the slice's 8 scale / shift
-// values in an LDS table (16-byte aligned), read at use so that they do not occupy registers across the kernel
+// ---------------------------------------------------------------------------------------------
+// Both kernels run out of VALU issue slots first (a wave64 instruction holds its SIMD for 4 cycles), so the two
+// activations are written for instruction count.  ReLU6 is carried as clamp01(z / 6): the clamp is the FMA's free output
+// modifier, and the factor 6 is pushed through the linear operators that follow -- the expand GEMM (h1 = 6 W1 a', so
+// GroupNorm-2 sees sums scaled by 6 / 36 and its affine is applied to acc' = acc / 6 with shift / 6) and the depthwise
+// conv (weights staged as 6 w).  In real arithmetic nothing changes; in T the rounding points move by one operation.
+// a' = clamp01(a * s + b) = relu6(norm1(a)) / 6 on one 16-byte operand slice (8 channels); sc / sh point at the slice's
+// 8 scale / shift values (already divided by 6) in an LDS table (16-byte aligned), read at use
 template <typename T>
 __device__ __forceinline__ typename Elem<T>::vec_t activate8(typename Elem<T>::vec_t v, const float* sc, const float* sh) {
-  float f[8];
-  vec_to_f32<T>(v, f);
+  const u32x4 x = reinterpret_cast<const u32x4&>(v);
   const f32x4 s0 = *reinterpret_cast<const f32x4*>(sc), s1 = *reinterpret_cast<const f32x4*>(sc + 4);
   const f32x4 b0 = *reinterpret_cast<const f32x4*>(sh), b1 = *reinterpret_cast<const f32x4*>(sh + 4);
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    f[e] = relu6f(f[e] * s0[e] + b0[e]);
-    f[4 + e] = relu6f(f[4 + e] * s1[e] + b1[e]);
-  }
-  return f32_to_vec<T>(f);
+  u32x4 o;
+  o[0] = act_clamp01_pack<T>(x[0], s0[0], s0[1], b0[0], b0[1]);
+  o[1] = act_clamp01_pack<T>(x[1], s0[2], s0[3], b0[2], b0[3]);
+  o[2] = act_clamp01_pack<T>(x[2], s1[0], s1[1], b1[0], b1[1]);
+  o[3] = act_clamp01_pack<T>(x[3], s1[2], s1[3], b1[2], b1[3]);
+  return reinterpret_cast<const typename Elem<T>::vec_t&>(o);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -82,7 +87,7 @@ __global__ void __launch_bounds__(256, 2) expand_stats_kernel(const IrbxArgs a, 
 #pragma unroll
     for (int s = 0; s < KS; ++s) wf[j][s] = ld_vec<T>(w1 + (size_t)((wave * NBW + j) * 32 + n) * K + 16 * s + 8 * h);
   for (int i = tid; i < K; i += 256) {
-    aff1[0][i] = a.as1[(size_t)b * K + i];
+    aff1[0][i] = a.as1[(size_t)b * K + i];   // already / 6 (GnFinalizeArgs::post_scale)
     aff1[1][i] = a.ab1[(size_t)b * K + i];
   }
   float s1[NBW], s2[NBW];
@@ -145,8 +150,8 @@ __global__ void __launch_bounds__(256, 2) expand_stats_kernel(const IrbxArgs a, 
     s2[j] += __shfl_xor(s2[j], 32, 64);
     if (h == 0) {
       const int c = (wave * NBW + j) * 32 + n;
-      a.stats[((size_t)(b * ntiles + tile) * 2 + 0) * a.Chid + c] = s1[j];
-      a.stats[((size_t)(b * ntiles + tile) * 2 + 1) * a.Chid + c] = s2[j];
+      a.stats[((size_t)(b * ntiles + tile) * 2 + 0) * a.Chid + c] = 6.f * s1[j];   // h1 = 6 W1 a'
+      a.stats[((size_t)(b * ntiles + tile) * 2 + 1) * a.Chid + c] = 36.f * s2[j];
     }
   }
 }
@@ -165,7 +170,8 @@ constexpr int SHP = 144;
 
 // STAMP = diagnostic build (llie_tune("irbx_stamp", 1)): s_memtime around the phases, summed per wave into a.dbg
 // ([workgroup][wave][4] = {tile prologue, MFMA phase, barrier wait, depthwise phase} cycles); never used in production.
-template <typename T, int KS, bool DBUF, bool STAMP = false>
+// ABL (diagnostic builds only): timing ablations -- 1 no h2 stores, 2 no pool sums, 8 no depthwise MFMAs.
+template <typename T, int KS, bool DBUF, bool STAMP = false, int ABL = 0>
 __global__ void __launch_bounds__(256, 2) expand_dw_kernel(const IrbxArgs a, const int tiles_per_wg, const int chunks_per_wg) {
   constexpr int K = 16 * KS;
   constexpr int XP = (K + 8) * 2;                        // sX pixel pitch in bytes (80 / 144 / 208 / 272: conflict-free ds_read_b128)
@@ -198,13 +204,13 @@ __global__ void __launch_bounds__(256, 2) expand_dw_kernel(const IrbxArgs a, con
   const int chunk1 = chunk0 + chunks_per_wg < nchunks_all ? chunk0 + chunks_per_wg : nchunks_all;
 
   // ---- per-workgroup constants: depthwise weights (packed T), affine tables of this image
-  for (int i = tid; i < 9 * a.Chid; i += 256) wds[i] = (T)a.wd[i];
+  for (int i = tid; i < 9 * a.Chid; i += 256) wds[i] = (T)(6.f * a.wd[i]);  // the tile in LDS holds relu6(.) / 6
   for (int i = tid; i < a.Chid; i += 256) {
-    aff2[i] = a.as2[(size_t)b * a.Chid + i];
-    aff2[a.Chid + i] = a.ab2[(size_t)b * a.Chid + i];
+    aff2[i] = a.as2[(size_t)b * a.Chid + i];                      // applied to acc' = acc / 6: scale unchanged,
+    aff2[a.Chid + i] = a.ab2[(size_t)b * a.Chid + i] * kSixth;    // shift / 6, result clamped to [0, 1]
   }
   for (int i = tid; i < K; i += 256) {
-    aff1[i] = a.as1[(size_t)b * K + i];
+    aff1[i] = a.as1[(size_t)b * K + i];      // already / 6 (GnFinalizeArgs::post_scale)
     aff1[K + i] = a.ab1[(size_t)b * K + i];
   }
   // pixels 180..191 of the last MFMA block do not exist: their operand rows stay zero
@@ -296,6 +302,7 @@ __global__ void __launch_bounds__(256, 2) expand_dw_kernel(const IrbxArgs a, con
     }
     if (PREF && tile + 1 < tile_last) load_tile(tile + 1);
     // validity of this lane's three halo pixels (zero padding of the depthwise input)
+    const bool border = ty == 0 || tx == 0 || ty == a.H / kXT_H - 1 || tx == tiles_x - 1;
     bool ok[3];
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
@@ -352,17 +359,16 @@ __global__ void __launch_bounds__(256, 2) expand_dw_kernel(const IrbxArgs a, con
         // that each lane owns 8 consecutive channels, two ds_write_b128
         uint32_t pk[4][2];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          typedef T t2 __attribute__((ext_vector_type(2)));
+        for (int g = 0; g < 4; ++g)
 #pragma unroll
-          for (int j = 0; j < 2; ++j) {
-            t2 o;
-            const float v0 = relu6f(acc[4 * g + 2 * j] * sc2[g][2 * j] + sh2[g][2 * j]);
-            const float v1 = relu6f(acc[4 * g + 2 * j + 1] * sc2[g][2 * j + 1] + sh2[g][2 * j + 1]);
-            o[0] = (T)v0;
-            o[1] = (T)v1;
-            pk[g][j] = ok[i] ? *reinterpret_cast<uint32_t*>(&o) : 0u;
-          }
+          for (int j = 0; j < 2; ++j)
+            pk[g][j] = affine_clamp01_pack<T>(acc[4 * g + 2 * j], acc[4 * g + 2 * j + 1], sc2[g][2 * j], sc2[g][2 * j + 1],
+                                              sh2[g][2 * j], sh2[g][2 * j + 1]);
+        if (border) {  // tiles on the image border: zero padding of the depthwise input (uniform branch, most tiles skip it)
+#pragma unroll
+          for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) pk[g][j] = ok[i] ? pk[g][j] : 0u;
         }
         u32x4 lo, hi2;
 #pragma unroll
@@ -391,11 +397,27 @@ __global__ void __launch_bounds__(256, 2) expand_dw_kernel(const IrbxArgs a, con
         f32x16 dacc[2];
 #pragma unroll
         for (int r = 0; r < 16; ++r) dacc[0][r] = dacc[1][r] = 0.f;
+        // The phase is LDS-latency bound unless the operand reads run well ahead of their MFMAs (two waves per SIMD hide
+        // little): all nine weights first, then the data operands of tap t + 1 are in flight while tap t multiplies.
+        uint32_t wv[9];
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) wv[tap] = *reinterpret_cast<const uint16_t*>(wcol + tap * a.Chid);
+        vec_t bf[2][4];
+        auto ld_tap = [&](int tap, vec_t (&bb)[4]) {
+          const int ky = tap / 3, kx = tap % 3;
+#pragma unroll
+          for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+              bb[blk * 2 + s2] = *reinterpret_cast<const vec_t*>(buf + (dq[blk] + ky * kXH_W + kx) * SHP + (chb * 4 + 2 * s2 + h) * 16);
+        };
+        ld_tap(0, bf[0]);
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
-          const int ky = tap / 3, kx = tap % 3;
-          const uint32_t wv = *reinterpret_cast<const uint16_t*>(wcol + tap * a.Chid);
-          const uint32_t wdup = wv | (wv << 16);
+          if (tap + 1 < 9) ld_tap(tap + 1, bf[(tap + 1) & 1]);
+          __builtin_amdgcn_sched_barrier(0);  // keep the look-ahead reads above this tap's MFMAs (the scheduler sinks them to
+                                              // their use otherwise: one or two reads in flight, the phase waits on LDS latency)
+          const uint32_t wdup = wv[tap] | (wv[tap] << 16);
           vec_t af[2];
 #pragma unroll
           for (int s2 = 0; s2 < 2; ++s2) {
@@ -405,12 +427,13 @@ __global__ void __launch_bounds__(256, 2) expand_dw_kernel(const IrbxArgs a, con
             af[s2] = reinterpret_cast<const vec_t&>(t);
           }
 #pragma unroll
-          for (int blk = 0; blk < 2; ++blk) {
-            const int q = dq[blk] + ky * kXH_W + kx;
+          for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2)
-              dacc[blk] = mfma16<T>(af[s2], *reinterpret_cast<const vec_t*>(buf + q * SHP + (chb * 4 + 2 * s2 + h) * 16), dacc[blk]);
-          }
+            for (int s2 = 0; s2 < 2; ++s2) {
+              const vec_t bv = bf[tap & 1][blk * 2 + s2];
+              if constexpr (!(ABL & 8)) dacc[blk] = mfma16<T>(af[s2], bv, dacc[blk]);
+              else asm volatile("" :: "v"(bv), "v"(af[s2]));
+            }
         }
         // accumulators: lane = pixel n of the block, 16 channels (r&3) + 8(r>>2) + 4h -> T, lane halves exchanged so that
         // each lane owns 8 consecutive channels, two 16-byte stores per block
@@ -437,34 +460,52 @@ __global__ void __launch_bounds__(256, 2) expand_dw_kernel(const IrbxArgs a, con
             hi2[j] = r13[0]; hi2[2 + j] = r13[1];
           }
           T* op = out + ((size_t)(y0 + drow[blk]) * a.W + x0p + (n & 15)) * a.Chid + chunk * 64 + chb * 32 + 16 * h;
-          *reinterpret_cast<u32x4*>(op) = lo;
-          *reinterpret_cast<u32x4*>(op + 8) = hi2;
+          if constexpr (!(ABL & 1)) {
+            *reinterpret_cast<u32x4*>(op) = lo;
+            *reinterpret_cast<u32x4*>(op + 8) = hi2;
+          } else {
+            asm volatile("" :: "v"(lo), "v"(hi2));
+          }
         }
         // SE pool partial of this (tile, chunk): the 16 channel values of a lane summed over the wave's 64 pixels -- the
         // two blocks in registers, then a halving butterfly over the 32 pixel lanes (lane n ends up with channel slot (n>>1)&15)
-        if (a.pool) {
+        if (a.pool && !(ABL & 2)) {
           float v[16];
 #pragma unroll
           for (int r = 0; r < 16; ++r) v[r] = dacc[0][r] + dacc[1][r];
-#pragma unroll
-          for (int lvl = 0; lvl < 4; ++lvl) {
-            const int bit = 16 >> lvl, half = 8 >> lvl;
-            // lane-dependent choice between two registers as a bit blend with an opaque all-ones / zero mask (v_bfi_b32):
-            // written as `up ? v[half + i] : v[i]` the compiler turns the four levels into a 16-way indexed select chain
-            uint32_t m = (n & bit) ? 0xFFFFFFFFu : 0u;
+          // halving butterfly over pixel-lane bits 4 and 3 (lane-dependent choice between two registers as a bit blend with an
+          // opaque all-ones / zero mask, v_bfi_b32: written as a ternary the compiler builds a 16-way indexed select chain);
+          // bit 4 crosses the 16-lane DPP rows (ds_swizzle, the only LDS round trip), bit 3 is a row rotate by 8
+          {
+            uint32_t m = (n & 16) ? 0xFFFFFFFFu : 0u;
             asm volatile("" : "+v"(m));
 #pragma unroll
-            for (int i = 0; i < half; ++i) {
-              const uint32_t lo = __float_as_uint(v[i]), hi = __float_as_uint(v[half + i]);
+            for (int i = 0; i < 8; ++i) {
+              const uint32_t lo = __float_as_uint(v[i]), hi = __float_as_uint(v[8 + i]);
               const float keep = __uint_as_float((hi & m) | (lo & ~m));
-              const float send = __uint_as_float((lo & m) | (hi & ~m));
-              v[i] = keep + __shfl_xor(send, bit, 64);
+              const int send = (int)((lo & m) | (hi & ~m));
+              v[i] = keep + __int_as_float(__builtin_amdgcn_ds_swizzle(send, 0x401F));  // lane ^ 16
+            }
+            m = (n & 8) ? 0xFFFFFFFFu : 0u;
+            asm volatile("" : "+v"(m));
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const uint32_t lo = __float_as_uint(v[i]), hi = __float_as_uint(v[4 + i]);
+              const float keep = __uint_as_float((hi & m) | (lo & ~m));
+              const int send = (int)((lo & m) | (hi & ~m));
+              v[i] = keep + __int_as_float(__builtin_amdgcn_update_dpp(0, send, 0x128, 0xF, 0xF, false));  // row_ror:8 = lane ^ 8
             }
           }
-          v[0] += __shfl_xor(v[0], 1, 64);
-          if ((n & 1) == 0) {
-            const int r = (n >> 1) & 15;
-            red[(DBUF ? par : 0) * 256 + wave * 64 + (r & 3) + 8 * (r >> 2) + 4 * h] = v[0];
+          // the 4 remaining values are complete sums over the 8 lanes that share bits 4..3: quad xor 1, quad xor 2, half mirror
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            v[i] += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v[i]), 0xB1, 0xF, 0xF, false));   // quad_perm [1,0,3,2]
+            v[i] += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v[i]), 0x4E, 0xF, 0xF, false));   // quad_perm [2,3,0,1]
+            v[i] += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v[i]), 0x141, 0xF, 0xF, false));  // row_half_mirror
+          }
+          if ((n & 7) == 0) {  // r = 8 b4 + 4 b3 + {0..3} -> channel slots 8 (2 b4 + b3) + 4 h + {0..3}: 16 contiguous bytes
+            f32x4 o = {v[0], v[1], v[2], v[3]};
+            *reinterpret_cast<f32x4*>(red + (DBUF ? par : 0) * 256 + wave * 64 + 8 * (n >> 3) + 4 * h) = o;
           }
           pend_tile = tile; pend_chunk = chunk; pend_par = DBUF ? par : 0;
         }
@@ -502,7 +543,8 @@ int irbx_stats_rows(int P) {
   return rp;
 }
 
-static int g_irbx_dbuf = 1, g_irbx_tiles = 4, g_irbx_stamp = 0;
+static int g_irbx_dbuf = 1, g_irbx_tiles = 4, g_irbx_stamp = 0, g_irbx_ablate = 0;
+void irbx_ablate(int v) { g_irbx_ablate = v; }
 static unsigned long long* g_irbx_dbg = nullptr;
 static size_t g_irbx_dbg_n = 0;  // entries of the last stamped launch
 void irbx_stamp(int v) { g_irbx_stamp = v; }
@@ -578,15 +620,21 @@ static hipError_t launch_dw_cfg(const IrbxArgs& a, hipStream_t s) {
       g_irbx_dbg_n = n;
       IrbxArgs b = a;
       b.dbg = g_irbx_dbg;
-      static bool attr2 = false;
-      if (!attr2) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&expand_dw_kernel<T, KS, DBUF, true>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+      auto go = [&](auto kern) -> hipError_t {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
         if (e != hipSuccess) return e;
-        attr2 = true;
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, b, tpw, cpw);
+        return hipGetLastError();
+      };
+      switch (a.ablate) {
+        case 0: return go(&expand_dw_kernel<T, KS, DBUF, true, 0>);
+        case 1: return go(&expand_dw_kernel<T, KS, DBUF, true, 1>);
+        case 2: return go(&expand_dw_kernel<T, KS, DBUF, true, 2>);
+        case 3: return go(&expand_dw_kernel<T, KS, DBUF, true, 3>);
+        case 8: return go(&expand_dw_kernel<T, KS, DBUF, true, 8>);
+        case 11: return go(&expand_dw_kernel<T, KS, DBUF, true, 11>);
       }
-      hipLaunchKernelGGL((expand_dw_kernel<T, KS, DBUF, true>), grid, dim3(256), lds, s, b, tpw, cpw);
-      return hipGetLastError();
+      return hipErrorInvalidValue;
     }
   }
   hipLaunchKernelGGL((expand_dw_kernel<T, KS, DBUF>), grid, dim3(256), lds, s, a, tpw, cpw);
@@ -611,8 +659,10 @@ static hipError_t launch_dw_t(const IrbxArgs& a, hipStream_t s) {
   }
   return hipErrorInvalidValue;
 }
-hipError_t launch_expand_dw(int dtype, const IrbxArgs& a, hipStream_t s) {
-  if (!irbx_supported(dtype, a.c0 + a.c1, a.c0, a.Chid, a.H, a.W) || (a.c1 && !a.x1) || !a.out) return hipErrorInvalidValue;
+hipError_t launch_expand_dw(int dtype, const IrbxArgs& a0, hipStream_t s) {
+  if (!irbx_supported(dtype, a0.c0 + a0.c1, a0.c0, a0.Chid, a0.H, a0.W) || (a0.c1 && !a0.x1) || !a0.out) return hipErrorInvalidValue;
+  IrbxArgs a = a0;
+  a.ablate = g_irbx_ablate;
   return dtype == 1 ? launch_dw_t<half_t>(a, s) : launch_dw_t<bf16_t>(a, s);
 }
 

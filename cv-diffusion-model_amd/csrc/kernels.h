@@ -6,7 +6,10 @@
 
 namespace llie {
 
-enum Act : int { ACT_NONE = 0, ACT_RELU6 = 1, ACT_SILU = 2 };
+// ACT_RELU6_S6 (pointwise GEMM prologue, 2-byte T): a' = clamp01(a * as + ab) with tables that ALREADY hold scale / 6 and
+// shift / 6 (GnFinalizeArgs::post_scale), i.e. relu6(.) / 6 for one FMA with a free clamp; the GEMM multiplies its
+// accumulators by 6 in the epilogue.  Every K-segment of such a GEMM must use it.
+enum Act : int { ACT_NONE = 0, ACT_RELU6 = 1, ACT_SILU = 2, ACT_RELU6_S6 = 3 };
 
 // Launchers of the profiled kernel classes record the name of the kernel they dispatched (template
 // arguments included, as rocprofv3 prints them) so that llie_profile_report can aggregate per kernel.
@@ -50,9 +53,6 @@ struct GemmArgs {
   const void* dot;    // optional [M][N] T: the slab then holds (sum out*dot, sum out) instead of (sum, sum of squares)
 };
 hipError_t launch_pw_gemm(int dtype, const GemmArgs& a, hipStream_t s);
-bool pw_gemm2_supported(int dtype, const GemmArgs& a);   // LDS-DMA pipelined variant (gemm2.hip)
-hipError_t launch_pw_gemm2(const GemmArgs& a, hipStream_t s);
-void pw_gemm_use_v2(int v);
 int pw_gemm_tile_rows(int P);  // BM used for a given P (stats slab tiles = P / BM)
 void pw_gemm_force_bk(int bk);  // tuning knob (0 = automatic)
 void pw_gemm_debug(int v);      // timing ablations; results are wrong when non-zero
@@ -77,6 +77,7 @@ struct GnFinalizeArgs {
   int Creal;         // 0 = C; otherwise the groups partition channels [0, Creal) and the rest (zero padding) gets a zero affine
   float* mean_out;   // optional [B][groups] (training: kept for the backward pass)
   float* rstd_out;
+  float post_scale;  // 0 = 1: as and ab are multiplied by it (1/6 for consumers that carry ReLU6 as clamp01(z / 6))
 };
 hipError_t launch_gn_finalize(const GnFinalizeArgs& a, hipStream_t s);
 
@@ -89,39 +90,29 @@ struct DwArgs {
   float* pool;
   int B, H, W, C;
   int no_act;        // 1: prologue is the affine alone (backward: dh2 = da3*gate + dmean/P), 0: affine + ReLU6
+  int s6;            // 1 (2-byte T, forward): as / ab hold scale / 6 and shift / 6 (GnFinalizeArgs::post_scale); the
+                     // prologue is clamp01(x * as + ab) = relu6(.) / 6 (one FMA, free clamp) and the weights are taken x 6
   // backward epilogue (all four set, pool null): out = conv * [0 < bx*bas + bab < 6], and
   // bslab[b][tile][0][c] = sum out, [1][c] = sum out*bx over 8-row segments (tile = dwconv_ntiles numbering)
   const void* bx; const float* bas; const float* bab; float* bslab;
 };
 hipError_t launch_dwconv3x3(int dtype, const DwArgs& a, hipStream_t s);
 
-// Fused expand + depthwise ("recompute" form, 2-byte T only): h2 = dw3x3(relu6(aff2(W1 . relu6(aff1(x))))).
-// The 4x-expanded tensor h1 is never stored: every workgroup recomputes the rows it needs with MFMA
-// from the narrow block input x (virtual concat of up to two NHWC tensors).
-struct DwxArgs {
-  const void* x0; const void* x1; int c0, c1;   // Cin = c0 + c1 in {32, 64, 96, 128}
-  const float* as1; const float* ab1;            // [B][Cin]   GroupNorm-1 affine (ReLU6 follows)
-  const void* w1;                                // [Chid][Cin] T
-  const float* as2; const float* ab2;            // [B][Chid]  GroupNorm-2 + FiLM affine (ReLU6 follows)
-  const float* wd;                               // [9][Chid] fp32 depthwise weights, tap-major
-  void* out; float* pool;
-  int B, H, W, Chid;
-};
-bool dwx_supported(int dtype, int Cin, int Chid, int H, int W);
-hipError_t launch_dwx(int dtype, const DwxArgs& a, hipStream_t s);
 // Recompute form of the block's front half (irbx.hip, 2-byte T): expand_stats writes only h1's statistics slab
 // ([B][P / irbx_stats_rows(P)][2][Chid]), expand_dw produces h2 and the SE pool slab ([B][irbx_pool_tiles][Chid]).
 struct IrbxArgs {
   const void* x0; const void* x1; int c0, c1;   // block input (virtual concat), Cin = c0 + c1 in {32, 64, 96, 128}
-  const float* as1; const float* ab1;            // [B][Cin]   GroupNorm-1 affine (ReLU6 follows)
+  const float* as1; const float* ab1;            // [B][Cin]   GroupNorm-1 affine DIVIDED BY 6 (post_scale): a' = clamp01(.) = relu6 / 6
   const void* w1;                                // [Chid][Cin] T
-  const float* as2; const float* ab2;            // [B][Chid]  GroupNorm-2 + FiLM affine (ReLU6 follows)
+  const float* as2; const float* ab2;            // [B][Chid]  GroupNorm-2 + FiLM affine (ReLU6 follows), undivided
   const float* wd;                               // [9][Chid] fp32 depthwise weights, tap-major
   void* out; float* pool;                        // expand_dw outputs
   float* stats;                                  // expand_stats output
   int B, H, W, Chid;
   unsigned long long* dbg;                       // diagnostic builds only (irbx_stamp)
+  int ablate;                                    // timing ablations (results wrong when non-zero; 0 in production)
 };
+void irbx_ablate(int v);
 void irbx_stamp(int v);
 hipError_t irbx_stamp_fetch(double* out4);
 bool irbx_supported(int dtype, int Cin, int c0, int Chid, int H, int W);

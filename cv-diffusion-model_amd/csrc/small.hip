@@ -88,6 +88,10 @@ __global__ void __launch_bounds__(256) gn_finalize_kernel(const GnFinalizeArgs a
       sc *= fs;
       sh = sh * fs + fh;
     }
+    if (a.post_scale != 0.f) {
+      sc *= a.post_scale;
+      sh *= a.post_scale;
+    }
     a.as[(size_t)b * a.C + c] = sc;
     a.ab[(size_t)b * a.C + c] = sh;
   }

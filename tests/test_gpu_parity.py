@@ -347,50 +347,6 @@ def test_fp32_full_resolution_b4_vs_b1(dev):
     assert torch.equal(full[2:3], one)
 
 
-def test_lds_dma_gemm_variant_agrees(dev):
-    """gemm2.hip (LDS-DMA ring, opt-in) vs the default register-staged GEMM: same MFMA arithmetic,
-    the only difference is the prologue's FMA in packed f16 instead of fp32."""
-    native = importlib.import_module("cv-diffusion-model_amd._native")
-    m, sd, spec = small_model(256, dev)
-    m.compute_dtype = "fp16"
-    try:
-        low = (torch.rand(2, 3, 256, 256, generator=torch.Generator().manual_seed(6)) * 2 - 1).to(dev)
-        noise = torch.randn(4, 2, 3, 256, 256, generator=torch.Generator().manual_seed(7)).to(dev)
-        outs = []
-        for v in (0, 1):
-            native.check(native.lib().llie_tune(b"gemm_v2", v))
-            o = m.enhance(low, 4, noise=noise, return_noise_pred=True)
-            outs.append((o.noise_pred[0].clone(), o.enhanced.clone()))
-        rel = max_abs(outs[0][0].cpu(), outs[1][0].cpu()) / outs[0][0].abs().max().item()
-        assert rel < 5e-3, rel
-        assert psnr01(outs[0][1].cpu(), outs[1][1].cpu()) > 45.0
-    finally:
-        native.check(native.lib().llie_tune(b"gemm_v2", 0))
-        m.compute_dtype = None
-
-
-def test_recompute_form_agrees_with_unfused_path(dev):
-    """dwx.hip (expand recomputed inside the depthwise kernel; opt-in) vs the default K1 -> depthwise
-    pair, fp16, same inputs: the two differ only by where h1 is rounded to fp16."""
-    native = importlib.import_module("cv-diffusion-model_amd._native")
-    m, sd, spec = small_model(256, dev)
-    m.compute_dtype = "fp16"
-    try:
-        low = (torch.rand(2, 3, 256, 256, generator=torch.Generator().manual_seed(4)) * 2 - 1).to(dev)
-        noise = torch.randn(4, 2, 3, 256, 256, generator=torch.Generator().manual_seed(5)).to(dev)
-        outs = []
-        for v in (0, 1):
-            native.check(native.lib().llie_tune(b"dwx", v))
-            o = m.enhance(low, 4, noise=noise, return_intermediate=True, return_noise_pred=True)
-            outs.append((o.noise_pred[0].clone(), o.enhanced.clone()))
-        rel = max_abs(outs[0][0].cpu(), outs[1][0].cpu()) / outs[0][0].abs().max().item()
-        assert rel < 5e-3, rel
-        assert psnr01(outs[0][1].cpu(), outs[1][1].cpu()) > 45.0
-    finally:
-        native.check(native.lib().llie_tune(b"dwx", 0))
-        m.compute_dtype = None
-
-
 # ------------------------------------------------------------------ error behaviour
 def test_error_behaviour(dev):
     m, sd, spec = small_model(64, dev)

@@ -18,12 +18,13 @@ N = importlib.import_module("cv-diffusion-model_amd._native")
 
 def main():
     a = [int(v) for v in sys.argv[1:]]
-    cin, cout, hw, b, split, reps, irbx, dbuf, stamp = (a + [32, 32, 256, 32, 0, 10, 1, 1, 0][len(a):])[:9]
+    cin, cout, hw, b, split, reps, irbx, dbuf, stamp, ablate = (a + [32, 32, 256, 32, 0, 10, 1, 1, 0, 0][len(a):])[:10]
     dev = torch.device("cuda:0")
     L = N.lib()
     N.check(L.llie_tune(b"irbx", irbx))
     N.check(L.llie_tune(b"irbx_dbuf", dbuf))
     N.check(L.llie_tune(b"irbx_stamp", stamp))
+    N.check(L.llie_tune(b"irbx_ablate", ablate))
     blk = M.InvertedResidualBlock(cin, cout, 128, concat_split=split).to(dev)
     blk.compute_dtype = "fp16"
     x = torch.rand(b, cin, hw, hw, device=dev) * 4 - 2
@@ -36,7 +37,7 @@ def main():
         for _ in range(reps):
             blk(x, te)
         torch.cuda.synchronize()
-    print(f"irb {cin}->{cout} {hw}x{hw} B={b} irbx={irbx} dbuf={dbuf}: {(time.perf_counter() - t0) / reps * 1e3:.3f} ms per block "
+    print(f"irb {cin}->{cout} {hw}x{hw} B={b} irbx={irbx} dbuf={dbuf} ablate={ablate}: {(time.perf_counter() - t0) / reps * 1e3:.3f} ms per block "
           f"(incl. NCHW<->NHWC conversion of the operator boundary)")
     if stamp:
         out = (C.c_double * 4)()

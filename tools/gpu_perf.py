@@ -59,30 +59,8 @@ def perf(dtype="fp16", B=32, size=256, variant="small", iters=5):
     sys.stdout.flush()
 
 
-def ab_dwx():
-    """fused expand+depthwise on/off in one process: output agreement and speed."""
-    L = N.lib()
-    m = M.LowLightDiffusion(unet_variant="small", image_size=256, compute_dtype="fp16").to(dev)
-    low = torch.rand(4, 3, 256, 256, device=dev) * 2 - 1
-    noise = torch.randn(4, 4, 3, 256, 256, device=dev)
-    outs = {}
-    for v in (0, 1):
-        L.llie_tune(b"dwx", v)
-        outs[v] = m.enhance(low, 4, noise=noise, return_intermediate=True).intermediate[-1]
-    d = (outs[0] - outs[1]).abs().max().item()
-    print(f"dwx on vs off (small@256 fp16 B=4): max-abs diff of final latents {d:.3e} (latent absmax {outs[0].abs().max().item():.1f})", flush=True)
-    for v in (0, 1, 0, 1):
-        L.llie_tune(b"dwx", v)
-        print(f"--- dwx={v}")
-        perf("fp16", 32, iters=3)
-    L.llie_tune(b"dwx", 0)
-
-
 if __name__ == "__main__":
     sanity()
-    if len(sys.argv) > 1 and sys.argv[1] == "dwx":
-        ab_dwx()
-        sys.exit(0)
     perf("fp16", 32)
     if len(sys.argv) > 1 and sys.argv[1] == "all":
         perf("fp32", 8)

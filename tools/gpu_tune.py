@@ -28,7 +28,7 @@ def time_it(fn, iters=10):
     return e0.elapsed_time(e1) / iters * 1e3  # us
 
 
-def gemm(kind, M, segs, Nout, P, dtype=1, B=32):
+def gemm(kind, M, segs, Nout, P, dtype=1, B=32, act=1):
     """kind 'k1': affine+relu6 prologue on all segs, stats; 'k3': gate on seg0, identity others, residual if 1 seg."""
     tdt = torch.float16 if dtype == 1 else torch.float32
     K = sum(segs)
@@ -44,7 +44,7 @@ def gemm(kind, M, segs, Nout, P, dtype=1, B=32):
     off = 0
     for i, c in enumerate(segs):
         if kind == "k1":
-            arr[i] = N.GemmSeg(a[i].data_ptr(), c, sc.data_ptr() + off * 4, bi.data_ptr() + off * 4, K, 1)
+            arr[i] = N.GemmSeg(a[i].data_ptr(), c, sc.data_ptr() + off * 4, bi.data_ptr() + off * 4, K, act)
         elif i == 0:
             arr[i] = N.GemmSeg(a[i].data_ptr(), c, sc.data_ptr(), None, K, 0)
         else:
@@ -91,19 +91,17 @@ SHAPES = [  # (name, kind, P, segs, N)   small@256, B=32
 if __name__ == "__main__":
     B = 32
     if "gemm" in sys.argv[1:]:
-        knobs = [("v1", 0), ("v1b", 0)]
+        knobs = [("relu6 fp32 prologue", 1), ("clamp01(z/6) prologue", 3), ("relu6 fp32 prologue", 1), ("clamp01(z/6) prologue", 3)]
         print(f"{'shape':28s} " + " ".join(f"{k:>26s}" for k, _ in knobs))
-        tot = {k: 0.0 for k, _ in knobs}
+        tot = {}
         for name, kind, P, segs, n in SHAPES:
             row = []
             for k, v in knobs:
-                L.llie_tune(b"gemm_v2", v)
-                us, gbs, tf = gemm(kind, B * P, segs, n, P)
-                tot[k] += us
+                us, gbs, tf = gemm(kind, B * P, segs, n, P, act=v)
+                tot[k] = tot.get(k, 0.0) + us
                 row.append(f"{us:8.1f}us {tf:4.0f}TF {gbs:5.0f}GB/s")
             print(f"{name:28s} " + " ".join(f"{r:>26s}" for r in row), flush=True)
         print("sum(us):", {k: round(v, 1) for k, v in tot.items()})
-        L.llie_tune(b"gemm_v2", 0)
     if "dw" in sys.argv[1:]:
         for rep in range(2):
             for H, Cc in [(256, 128), (256, 384), (128, 768), (64, 1536)]:
