@@ -523,7 +523,7 @@ int build_module(llie_ctx* c) {
 // Recompute form (irbx.hip: statistics-only expand + tile-fused expand/depthwise): default for the
 // inference path of 2-byte engines wherever irbx_supported(); llie_tune("irbx", 0) restores the unfused pair.
 int g_use_irbx = getenv("LLIE_NO_IRBX") ? 0 : 1;
-int g_se_fused = 1;  // narrow blocks: the SE MLP in one launch (se_fused_kernel); llie_tune("se_fused", 0) = three-kernel chain
+int g_se_fused = 0;  // narrow blocks: the SE MLP in one launch (se_fused_kernel); llie_tune("se_fused", 0) = three-kernel chain
 // Backward pass: run the weight-gradient kernels on a side stream next to the activation-gradient chain
 // (llie_tune("bwd_async", 0) puts everything back on the caller's stream).
 int g_bwd_async = 1;
@@ -2092,6 +2092,7 @@ int llie_tune(const char* knob, int value) {
   if (!strcmp(knob, "irbx_tiles")) { irbx_tune(-1, value); return LLIE_OK; }
   if (!strcmp(knob, "irbx_stamp")) { irbx_stamp(value); return LLIE_OK; }
   if (!strcmp(knob, "irbx_ablate")) { irbx_ablate(value); return LLIE_OK; }
+  if (!strcmp(knob, "irbx_ws")) { irbx_ws(value); return LLIE_OK; }
   if (!strcmp(knob, "se_fused")) { g_se_fused = value; return LLIE_OK; }
   if (!strcmp(knob, "gemm_ablate")) { pw_gemm_debug(value); return LLIE_OK; }
   if (!strcmp(knob, "dw_ablate")) { dwconv_debug(value); return LLIE_OK; }

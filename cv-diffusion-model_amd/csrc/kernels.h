@@ -113,6 +113,7 @@ struct IrbxArgs {
   int ablate;                                    // timing ablations (results wrong when non-zero; 0 in production)
 };
 void irbx_ablate(int v);
+void irbx_ws(int v);  // 1 (default): the wave-specialised expand_dw kernel
 void irbx_stamp(int v);
 hipError_t irbx_stamp_fetch(double* out4);
 bool irbx_supported(int dtype, int Cin, int c0, int Chid, int H, int W);
