@@ -330,10 +330,10 @@ def main() -> None:
     log(f"timed region done: {elapsed:.3f} s for {args.steps} steps")
     breakdown, dom_prof = None, None
     if prof:
+        # (rank 0 only: these passes call the model directly -- no collective, the other ranks are not here)
         # pass 1 (one step): every kernel class bracketed by HIP events on the launch stream -> which kernel dominates
         handle.profile_begin(ALL_CLASSES)
-        step()
-        drain()
+        model.enhance(low, args.lcm_steps)
         torch.cuda.synchronize()
         breakdown = handle.profile_report()
         dom_name = max(breakdown, key=lambda k: breakdown[k][0])
@@ -341,8 +341,7 @@ def main() -> None:
         # pass 2 (`--steps` steps): only the dominant kernel's launches bracketed, so that nothing else perturbs them
         handle.profile_begin(dom_class)
         for _ in range(args.steps):
-            step()
-        drain()
+            model.enhance(low, args.lcm_steps)
         torch.cuda.synchronize()
         dom_prof = handle.profile_report()
         dom_prof = {k: v for k, v in dom_prof.items() if k == dom_name} or dom_prof

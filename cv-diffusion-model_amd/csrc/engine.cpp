@@ -523,15 +523,15 @@ int build_module(llie_ctx* c) {
 // Recompute form (irbx.hip: statistics-only expand + tile-fused expand/depthwise): default for the
 // inference path of 2-byte engines wherever irbx_supported(); llie_tune("irbx", 0) restores the unfused pair.
 int g_use_irbx = getenv("LLIE_NO_IRBX") ? 0 : 1;
-int g_se_fused = 0;  // narrow blocks: the SE MLP in one launch (se_fused_kernel); llie_tune("se_fused", 0) = three-kernel chain
 // Backward pass: run the weight-gradient kernels on a side stream next to the activation-gradient chain
 // (llie_tune("bwd_async", 0) puts everything back on the caller's stream).
 int g_bwd_async = 1;
-// hipGraph path of llie_enhance: capture the batch as two concurrent half-batch branches.  Measured +4 % at B=32
-// (769 -> 799 img/s) and -6 % at B=8; off by default because the overlapping kernels stretch each other, which would
-// make the per-kernel durations that bench.py and rocprofv3 report (the roofline evidence) a function of the overlap
-// rather than of the kernel -- opt in with llie_tune("enhance_split", 1) when only throughput matters.
-int g_enhance_split = 0;
+// hipGraph path of llie_enhance: batches of 16 and more are captured as two concurrent half-batch branches (no operator
+// mixes samples and every kernel is bitwise batch-invariant, so the bits do not change): the launch-bound tail of one
+// half (norm finalisation, SE MLP) overlaps the streaming kernels of the other, +4 % at B = 32.  Overlapping kernels
+// stretch each other, so per-kernel durations are only meaningful from a single chain: llie_profile_* already forces
+// the eager single chain, and LLIE_ENHANCE_SPLIT=0 (or llie_tune("enhance_split", 0)) gives rocprofv3 the same.
+int g_enhance_split = getenv("LLIE_ENHANCE_SPLIT") ? atoi(getenv("LLIE_ENHANCE_SPLIT")) : 1;
 // Captured graphs bake in the kernel choices of the moment: every llie_tune call starts a new epoch of the graph cache.
 int g_tune_epoch = 0;
 int tune_epoch() { return g_tune_epoch; }
@@ -681,7 +681,6 @@ struct Run {
       e.w1 = wptr(w.se_w1); e.b1 = wptr<float>(w.se_b1); e.w2 = wptr(w.se_w2); e.b2 = wptr<float>(w.se_b2);
       e.mean = p<float>(semean); e.hid = p<float>(sehid); e.gate = p<float>(gate); e.B = B; e.C = w.hid; e.Cs = w.sq;
       timed(LLIE_K_SE, ((int64_t)B * dnt * w.hid * 4) + 2LL * w.hid * w.sq * (int64_t)es(), [&] {
-        if (g_se_fused && se_fused_supported(e)) return launch_se_fused(dt, e, s);
         hipError_t r1 = launch_se_fc1(dt, e, s);
         return r1 != hipSuccess ? r1 : launch_se_fc2(dt, e, s);
       });
@@ -2092,8 +2091,7 @@ int llie_tune(const char* knob, int value) {
   if (!strcmp(knob, "irbx_tiles")) { irbx_tune(-1, value); return LLIE_OK; }
   if (!strcmp(knob, "irbx_stamp")) { irbx_stamp(value); return LLIE_OK; }
   if (!strcmp(knob, "irbx_ablate")) { irbx_ablate(value); return LLIE_OK; }
-  if (!strcmp(knob, "irbx_ws")) { irbx_ws(value); return LLIE_OK; }
-  if (!strcmp(knob, "se_fused")) { g_se_fused = value; return LLIE_OK; }
+  if (!strcmp(knob, "gemm_stamp")) { pw_gemm_stamp(value); return LLIE_OK; }
   if (!strcmp(knob, "gemm_ablate")) { pw_gemm_debug(value); return LLIE_OK; }
   if (!strcmp(knob, "dw_ablate")) { dwconv_debug(value); return LLIE_OK; }
   if (!strcmp(knob, "dw_swap")) { dwconv_swap(value); return LLIE_OK; }
@@ -2103,6 +2101,12 @@ int llie_tune(const char* knob, int value) {
   return LLIE_ERR_ARG;
 }
 
+int llie_debug_gemm_stamps(double* out3) {
+  if (!out3) return LLIE_ERR_ARG;
+  hipError_t e = hipDeviceSynchronize();
+  if (e == hipSuccess) e = pw_gemm_stamp_fetch(out3);
+  return e == hipSuccess ? LLIE_OK : LLIE_ERR_ARG;
+}
 // diagnostic: mean per-wave cycles of the last stamped expand_dw launch (llie_tune("irbx_stamp", 1)); synchronises
 int llie_debug_irbx_stamps(double* out4) {
   if (!out4) return LLIE_ERR_ARG;

@@ -17,8 +17,12 @@
 
 namespace llie {
 
-template <typename T, int BM, int BN, int WM, int WN, int BK>
+// STAMP: diagnostic build (llie_tune("gemm_stamp", 1)): s_memtime per wave at kernel start / after the K loop / at the end,
+// summed into g.stamps[0..2] = {K loop, epilogue, waves}; never used in production.
+template <typename T, int BM, int BN, int WM, int WN, int BK, bool STAMP = false>
 __global__ void __launch_bounds__(WM* WN * 64) pw_gemm_kernel(const GemmArgs g) {
+  unsigned long long t_start = 0, t_loop = 0;
+  if constexpr (STAMP) t_start = __builtin_amdgcn_s_memtime();
   constexpr int NT = WM * WN * 64;
   constexpr int VEC = Elem<T>::VEC;
   constexpr int VPR = BK / VEC;  // 16-byte vectors per BK-wide k-chunk row
@@ -179,6 +183,7 @@ __global__ void __launch_bounds__(WM* WN * 64) pw_gemm_kernel(const GemmArgs g) 
     __syncthreads();
   }
 
+  if constexpr (STAMP) t_loop = __builtin_amdgcn_s_memtime();
   // ---- epilogue: accumulators -> LDS (fp32) -> 16-byte row vectors (+bias, +residual, stats) -> HBM.
   // One pass per 32-row MFMA block index `pi`: the C staging tile holds only WM*32 rows, which keeps the
   // kernel's LDS footprint small enough for 4 workgroups per CU (the full-resolution layers are
@@ -287,6 +292,28 @@ __global__ void __launch_bounds__(WM* WN * 64) pw_gemm_kernel(const GemmArgs g) 
       }
     }
   }
+  if constexpr (STAMP) {
+    if (g.stamps && (threadIdx.x & 63) == 0) {
+      const unsigned long long t_end = __builtin_amdgcn_s_memtime();
+      atomicAdd(&g.stamps[0], t_loop - t_start);
+      atomicAdd(&g.stamps[1], t_end - t_loop);
+      atomicAdd(&g.stamps[2], 1ull);
+    }
+  }
+}
+
+static int g_gemm_stamp = 0;
+static unsigned long long* g_gemm_stamps = nullptr;
+void pw_gemm_stamp(int v) { g_gemm_stamp = v; }
+hipError_t pw_gemm_stamp_fetch(double* out3) {  // mean cycles per wave of the last stamped launch: {K loop, epilogue}, and the wave count
+  if (!g_gemm_stamps) return hipErrorInvalidValue;
+  unsigned long long h[3];
+  hipError_t e = hipMemcpy(h, g_gemm_stamps, sizeof h, hipMemcpyDeviceToHost);
+  if (e != hipSuccess) return e;
+  out3[0] = h[2] ? (double)h[0] / (double)h[2] : 0.0;
+  out3[1] = h[2] ? (double)h[1] / (double)h[2] : 0.0;
+  out3[2] = (double)h[2];
+  return hipSuccess;
 }
 
 template <typename T, int BM, int BN, int WM, int WN, int BK>
@@ -304,6 +331,18 @@ static hipError_t launch_cfg(const GemmArgs& a, hipStream_t s) {
     attr_done = true;
   }
   const unsigned grid = (unsigned)((a.M / BM) * (a.N / BN));
+  if constexpr (sizeof(T) == 2 && BM == 128) {
+    if (g_gemm_stamp) {
+      if (!g_gemm_stamps && hipMalloc(reinterpret_cast<void**>(&g_gemm_stamps), 3 * sizeof(unsigned long long)) != hipSuccess) return hipErrorOutOfMemory;
+      (void)hipMemsetAsync(g_gemm_stamps, 0, 3 * sizeof(unsigned long long), s);
+      GemmArgs b = a;
+      b.stamps = g_gemm_stamps;
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pw_gemm_kernel<T, BM, BN, WM, WN, BK, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL((pw_gemm_kernel<T, BM, BN, WM, WN, BK, true>), dim3(grid), dim3(NT), lds, s, b);
+      return hipGetLastError();
+    }
+  }
   static const std::string name = std::string("pw_gemm_kernel<") + TypeName<T>::value + ", " + std::to_string(BM) + ", " +
                                   std::to_string(BN) + ", " + std::to_string(WM) + ", " + std::to_string(WN) + ", " +
                                   std::to_string(BK) + ">";

@@ -528,266 +528,6 @@ __global__ void __launch_bounds__(256, 2) expand_dw_kernel(const IrbxArgs a, con
 }
 
 // ---------------------------------------------------------------------------------------------
-// (3) the same operator, wave-specialised: 7 waves per workgroup in two roles that meet at ONE barrier per (tile, chunk).
-//   waves 0..2 "expand":    own two 32-pixel blocks of the halo tile each.  Their activated x slices (the MFMA B operands)
-//                           live in REGISTERS for the whole tile -- loaded straight from HBM in operand shape, so there
-//                           is no shared x tile and no second barrier -- and per chunk they run the 4 expand tiles
-//                           (2 pixel blocks x 2 channel blocks), aff2 + clamp, and park the result in sH[slot & 1];
-//   waves 3..6 "depthwise": the diagonal-MFMA depthwise conv of the PREVIOUS slot from sH[(slot - 1) & 1], the h2 stores
-//                           and the SE pool partials.
-// The expand role is the lighter one and hides behind the depthwise role; VALU work of one role overlaps the matrix
-// work of the other on the same SIMD, and the workgroup keeps 3.5 waves per SIMD resident at <= 128 registers.
-template <typename T, int KS>
-__global__ void __launch_bounds__(448, KS <= 4 ? 4 : 2) expand_dw_ws_kernel(const IrbxArgs a, const int tiles_per_wg, const int chunks_per_wg) {
-  constexpr int K = 16 * KS;
-  constexpr int SH_BYTES = kXNPB * 32 * SHP;
-  constexpr bool PREF = KS <= 2;  // next tile's x slices prefetched (registers)
-  typedef typename Elem<T>::vec_t vec_t;
-  extern __shared__ __align__(16) unsigned char smem[];
-  // [sH: 2 x 192 x SHP][wds: 9 x Chid T][aff2: 2 x Chid fp32][aff1: 2 x K fp32][red: 2 x 4 x 32 fp32]
-  unsigned char* sH = smem;
-  T* wds = reinterpret_cast<T*>(smem + 2 * SH_BYTES);
-  float* aff2 = reinterpret_cast<float*>(wds + 9 * a.Chid);
-  float* aff1 = aff2 + 2 * a.Chid;
-  float* red = aff1 + 2 * K;
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int n = lane & 31, h = lane >> 5;
-  const int b = blockIdx.z;
-  const int tiles_x = a.W / kXT_W;
-  const int P = a.H * a.W;
-  const int chunk0 = blockIdx.y * chunks_per_wg;
-  const int nchunks_all = a.Chid / 64;
-  const int nch = (chunk0 + chunks_per_wg < nchunks_all ? chunks_per_wg : nchunks_all - chunk0);
-  const int tile_first = blockIdx.x * tiles_per_wg;
-  const int ntiles_img = tiles_x * (a.H / kXT_H);
-  const int ntl = tile_first + tiles_per_wg < ntiles_img ? tiles_per_wg : ntiles_img - tile_first;
-  const int S = ntl * nch;  // slots of this workgroup
-
-  for (int i = tid; i < 9 * a.Chid; i += 448) wds[i] = (T)(6.f * a.wd[i]);  // the tile in LDS holds relu6(.) / 6
-  for (int i = tid; i < a.Chid; i += 448) {
-    aff2[i] = a.as2[(size_t)b * a.Chid + i];
-    aff2[a.Chid + i] = a.ab2[(size_t)b * a.Chid + i] * kSixth;
-  }
-  for (int i = tid; i < K; i += 448) {
-    aff1[i] = a.as1[(size_t)b * K + i];   // already / 6 (GnFinalizeArgs::post_scale)
-    aff1[K + i] = a.ab1[(size_t)b * K + i];
-  }
-  __syncthreads();
-
-  if (wave < 3) {
-    // ================================================================= expand role
-    const T* x0 = reinterpret_cast<const T*>(a.x0) + (size_t)b * P * a.c0;
-    const T* x1 = a.x1 ? reinterpret_cast<const T*>(a.x1) + (size_t)b * P * a.c1 : nullptr;
-    const T* w1 = reinterpret_cast<const T*>(a.w1);
-    vec_t raw[2][KS], xf[2][KS];
-    bool okn[2] = {false, false}, ok[2] = {false, false};
-    auto load_tile = [&](int tile) {
-      const int ty = tile / tiles_x, tx = tile % tiles_x;
-#pragma unroll
-      for (int blk = 0; blk < 2; ++blk) {
-        const int q = (2 * wave + blk) * 32 + n;
-        const int gy = ty * kXT_H - 1 + q / kXH_W, gx = tx * kXT_W - 1 + q % kXH_W;
-        okn[blk] = q < kXNPX && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-        const size_t pix = okn[blk] ? (size_t)gy * a.W + gx : 0;  // clamped: always a valid address, value unused
-#pragma unroll
-        for (int s = 0; s < KS; ++s) {
-          const int k = 16 * s + 8 * h;
-          raw[blk][s] = k < a.c0 ? ld_vec<T>(x0 + pix * a.c0 + k) : ld_vec<T>(x1 + pix * a.c1 + (k - a.c0));
-        }
-      }
-    };
-    if (PREF && S > 0) load_tile(tile_first);
-    for (int k = 0; k < S; ++k) {
-      const int tile = tile_first + k / nch, chunk = chunk0 + k % nch;
-      unsigned char* buf = sH + (k & 1) * SH_BYTES;
-      if (k % nch == 0) {  // new tile: activate this wave's x slices (norm1 + ReLU6 as clamp01(z / 6)), prefetch the next tile
-        if (!PREF) load_tile(tile);
-#pragma unroll
-        for (int blk = 0; blk < 2; ++blk) {
-          ok[blk] = okn[blk];
-#pragma unroll
-          for (int s = 0; s < KS; ++s) xf[blk][s] = activate8<T>(raw[blk][s], aff1 + 16 * s + 8 * h, aff1 + K + 16 * s + 8 * h);
-        }
-        if (PREF && k + nch < S) load_tile(tile + 1);
-      }
-#pragma unroll
-      for (int cb = 0; cb < 2; ++cb) {
-        const int ch0 = chunk * 64 + cb * 32;
-        vec_t wf[KS];
-#pragma unroll
-        for (int s = 0; s < KS; ++s) wf[s] = ld_vec<T>(w1 + (size_t)(ch0 + n) * K + 16 * s + 8 * h);
-#pragma unroll
-        for (int blk = 0; blk < 2; ++blk) {
-          const int q = (2 * wave + blk) * 32 + n;
-          f32x16 acc;
-#pragma unroll
-          for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-#pragma unroll
-          for (int s = 0; s < KS; ++s) acc = mfma16<T>(wf[s], xf[blk][s], acc);
-          uint32_t pk[4][2];
-#pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            // aff2 of the 4 accumulator channels ch0 + 8g + 4h + e, read at use (8 registers live instead of 32)
-            const f32x4 sc2 = *reinterpret_cast<const f32x4*>(aff2 + ch0 + 8 * g + 4 * h);
-            const f32x4 sh2 = *reinterpret_cast<const f32x4*>(aff2 + a.Chid + ch0 + 8 * g + 4 * h);
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-              const uint32_t v = affine_clamp01_pack<T>(acc[4 * g + 2 * j], acc[4 * g + 2 * j + 1], sc2[2 * j], sc2[2 * j + 1],
-                                                        sh2[2 * j], sh2[2 * j + 1]);
-              pk[g][j] = ok[blk] ? v : 0u;  // zero padding of the depthwise input outside the image (and pixels 180..191)
-            }
-          }
-          u32x4 lo, hi2;
-#pragma unroll
-          for (int j = 0; j < 2; ++j) {
-            const u32x2 r02 = __builtin_amdgcn_permlane32_swap(pk[0][j], pk[2][j], false, false);
-            const u32x2 r13 = __builtin_amdgcn_permlane32_swap(pk[1][j], pk[3][j], false, false);
-            lo[j] = r02[0]; lo[2 + j] = r02[1];
-            hi2[j] = r13[0]; hi2[2 + j] = r13[1];
-          }
-          *reinterpret_cast<u32x4*>(buf + q * SHP + (cb * 4 + 2 * h) * 16) = lo;
-          *reinterpret_cast<u32x4*>(buf + q * SHP + (cb * 4 + 2 * h + 1) * 16) = hi2;
-        }
-      }
-      __syncthreads();  // barrier k: slot k is complete in sH[k & 1]
-    }
-    __syncthreads();    // barrier S (the depthwise role's last pool flush)
-  } else {
-    // ================================================================= depthwise role
-    const int d = wave - 3, chb = d & 1, pxg = d >> 1;
-    T* out = reinterpret_cast<T*>(a.out) + (size_t)b * P * a.Chid;
-    uint32_t dmask[2][4];
-#pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-      for (int dd = 0; dd < 4; ++dd)
-        dmask[s2][dd] = ((n >> 3) == 2 * s2 + h && ((n & 7) >> 1) == dd) ? ((n & 1) ? 0xFFFF0000u : 0x0000FFFFu) : 0u;
-    int dq[2], drow[2];
-#pragma unroll
-    for (int blk = 0; blk < 2; ++blk) {
-      drow[blk] = 2 * (2 * pxg + blk) + (n >> 4);
-      dq[blk] = drow[blk] * kXH_W + (n & 15);
-    }
-    const int dtid = tid - 192;  // 0..255 inside the role
-    auto flush_pool = [&](int k) {  // pool partial of slot k: the two pixel groups of each channel block, fixed order
-      if (a.pool && dtid < 64) {
-        const int tile = tile_first + k / nch, chunk = chunk0 + k % nch;
-        const float* r = red + (k & 1) * 128;
-        const int cbb = dtid >> 5, ci = dtid & 31;
-        a.pool[((size_t)b * ntiles_img + tile) * a.Chid + chunk * 64 + dtid] = r[cbb * 32 + ci] + r[(cbb + 2) * 32 + ci];
-      }
-    };
-    for (int k = 0; k < S; ++k) {
-      __syncthreads();  // barrier k
-      if (k > 0) flush_pool(k - 1);
-      const int tile = tile_first + k / nch, chunk = chunk0 + k % nch;
-      const int ty = tile / tiles_x, tx = tile % tiles_x;
-      const int y0 = ty * kXT_H, x0p = tx * kXT_W;
-      const unsigned char* buf = sH + (k & 1) * SH_BYTES;
-      const T* wcol = wds + chunk * 64 + chb * 32 + n;
-      f32x16 dacc[2];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) dacc[0][r] = dacc[1][r] = 0.f;
-      uint32_t wv[9];
-#pragma unroll
-      for (int tap = 0; tap < 9; ++tap) wv[tap] = *reinterpret_cast<const uint16_t*>(wcol + tap * a.Chid);
-      vec_t bf[2][4];
-      auto ld_tap = [&](int tap, vec_t (&bb)[4]) {
-        const int ky = tap / 3, kx = tap % 3;
-#pragma unroll
-        for (int blk = 0; blk < 2; ++blk)
-#pragma unroll
-          for (int s2 = 0; s2 < 2; ++s2)
-            bb[blk * 2 + s2] = *reinterpret_cast<const vec_t*>(buf + (dq[blk] + ky * kXH_W + kx) * SHP + (chb * 4 + 2 * s2 + h) * 16);
-      };
-      ld_tap(0, bf[0]);
-#pragma unroll
-      for (int tap = 0; tap < 9; ++tap) {
-        if (tap + 1 < 9) ld_tap(tap + 1, bf[(tap + 1) & 1]);
-        __builtin_amdgcn_sched_barrier(0);  // look-ahead reads stay above this tap's MFMAs
-        const uint32_t wdup = wv[tap] | (wv[tap] << 16);
-        vec_t af[2];
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-          u32x4 t;
-#pragma unroll
-          for (int dd = 0; dd < 4; ++dd) t[dd] = wdup & dmask[s2][dd];
-          af[s2] = reinterpret_cast<const vec_t&>(t);
-        }
-#pragma unroll
-        for (int blk = 0; blk < 2; ++blk)
-#pragma unroll
-          for (int s2 = 0; s2 < 2; ++s2) dacc[blk] = mfma16<T>(af[s2], bf[tap & 1][blk * 2 + s2], dacc[blk]);
-      }
-#pragma unroll
-      for (int blk = 0; blk < 2; ++blk) {
-        uint32_t pk[4][2];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          typedef T t2 __attribute__((ext_vector_type(2)));
-#pragma unroll
-          for (int j = 0; j < 2; ++j) {
-            t2 o;
-            o[0] = (T)dacc[blk][4 * g + 2 * j];
-            o[1] = (T)dacc[blk][4 * g + 2 * j + 1];
-            pk[g][j] = *reinterpret_cast<uint32_t*>(&o);
-          }
-        }
-        u32x4 lo, hi2;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          const u32x2 r02 = __builtin_amdgcn_permlane32_swap(pk[0][j], pk[2][j], false, false);
-          const u32x2 r13 = __builtin_amdgcn_permlane32_swap(pk[1][j], pk[3][j], false, false);
-          lo[j] = r02[0]; lo[2 + j] = r02[1];
-          hi2[j] = r13[0]; hi2[2 + j] = r13[1];
-        }
-        T* op = out + ((size_t)(y0 + drow[blk]) * a.W + x0p + (n & 15)) * a.Chid + chunk * 64 + chb * 32 + 16 * h;
-        *reinterpret_cast<u32x4*>(op) = lo;
-        *reinterpret_cast<u32x4*>(op + 8) = hi2;
-      }
-      if (a.pool) {
-        float v[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) v[r] = dacc[0][r] + dacc[1][r];
-        {
-          uint32_t m = (n & 16) ? 0xFFFFFFFFu : 0u;
-          asm volatile("" : "+v"(m));
-#pragma unroll
-          for (int i = 0; i < 8; ++i) {
-            const uint32_t lo = __float_as_uint(v[i]), hi = __float_as_uint(v[8 + i]);
-            const float keep = __uint_as_float((hi & m) | (lo & ~m));
-            const int send = (int)((lo & m) | (hi & ~m));
-            v[i] = keep + __int_as_float(__builtin_amdgcn_ds_swizzle(send, 0x401F));  // lane ^ 16
-          }
-          m = (n & 8) ? 0xFFFFFFFFu : 0u;
-          asm volatile("" : "+v"(m));
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const uint32_t lo = __float_as_uint(v[i]), hi = __float_as_uint(v[4 + i]);
-            const float keep = __uint_as_float((hi & m) | (lo & ~m));
-            const int send = (int)((lo & m) | (hi & ~m));
-            v[i] = keep + __int_as_float(__builtin_amdgcn_update_dpp(0, send, 0x128, 0xF, 0xF, false));  // row_ror:8 = lane ^ 8
-          }
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          v[i] += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v[i]), 0xB1, 0xF, 0xF, false));   // quad_perm [1,0,3,2]
-          v[i] += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v[i]), 0x4E, 0xF, 0xF, false));   // quad_perm [2,3,0,1]
-          v[i] += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v[i]), 0x141, 0xF, 0xF, false));  // row_half_mirror
-        }
-        if ((n & 7) == 0) {
-          f32x4 o = {v[0], v[1], v[2], v[3]};
-          *reinterpret_cast<f32x4*>(red + (k & 1) * 128 + d * 32 + 8 * (n >> 3) + 4 * h) = o;
-        }
-      }
-    }
-    __syncthreads();  // barrier S
-    if (S > 0) flush_pool(S - 1);
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
 int irbx_stats_rows(int P);
 bool irbx_supported(int dtype, int Cin, int c0, int Chid, int H, int W) {
   if (dtype != 1 && dtype != 2) return false;
@@ -900,38 +640,9 @@ static hipError_t launch_dw_cfg(const IrbxArgs& a, hipStream_t s) {
   hipLaunchKernelGGL((expand_dw_kernel<T, KS, DBUF>), grid, dim3(256), lds, s, a, tpw, cpw);
   return hipGetLastError();
 }
-static int g_irbx_ws = 1;
-void irbx_ws(int v) { g_irbx_ws = v; }
-template <typename T, int KS>
-static hipError_t launch_dw_ws(const IrbxArgs& a, hipStream_t s) {
-  const size_t lds = (size_t)2 * kXNPB * 32 * SHP + (size_t)9 * a.Chid * 2 + (size_t)2 * a.Chid * 4 + (size_t)2 * 16 * KS * 4 + 2 * 128 * 4;
-  static bool attr_done = false;
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&expand_dw_ws_kernel<T, KS>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-    if (e != hipSuccess) return e;
-    attr_done = true;
-  }
-  const int ntiles = irbx_pool_tiles(a.H, a.W), nchunks = a.Chid / 64;
-  int tpw = g_irbx_tiles;
-  while (tpw > 1 && ((a.W / kXT_W) % tpw || (long)(ntiles / tpw) * a.B < 2048)) tpw >>= 1;
-  int cpw = nchunks;
-  while (cpw > 1 && (long)(ntiles / tpw) * a.B * (nchunks / cpw) < 1024 && cpw % 2 == 0) cpw >>= 1;
-  static const std::string name = std::string("expand_dw_ws_kernel<") + TypeName<T>::value + ", " + std::to_string(KS) + ">";
-  note_kernel(name.c_str());
-  hipLaunchKernelGGL((expand_dw_ws_kernel<T, KS>), dim3(ntiles / tpw, nchunks / cpw, a.B), dim3(448), lds, s, a, tpw, cpw);
-  return hipGetLastError();
-}
 template <typename T>
 static hipError_t launch_dw_t(const IrbxArgs& a, hipStream_t s) {
   const int Cin = a.c0 + a.c1;
-  if (g_irbx_ws && !g_irbx_stamp) {
-    switch (Cin) {
-      case 32: return launch_dw_ws<T, 2>(a, s);
-      case 64: return launch_dw_ws<T, 4>(a, s);
-      case 96: return launch_dw_ws<T, 6>(a, s);
-    }
-  }
   // double-buffered h1 tile (one barrier per chunk) while two workgroups still fit a CU's 160 KB of LDS
   if (g_irbx_dbuf) {
     switch (Cin) {

@@ -51,7 +51,10 @@ struct GemmArgs {
   int nostore;        // 1: compute and write only the statistics slab (out may be null)
   int dbg;            // timing ablations (set by the launcher from pw_gemm_debug; 0 in production)
   const void* dot;    // optional [M][N] T: the slab then holds (sum out*dot, sum out) instead of (sum, sum of squares)
+  unsigned long long* stamps;  // diagnostic builds only (pw_gemm_stamp)
 };
+void pw_gemm_stamp(int v);
+hipError_t pw_gemm_stamp_fetch(double* out3);
 hipError_t launch_pw_gemm(int dtype, const GemmArgs& a, hipStream_t s);
 int pw_gemm_tile_rows(int P);  // BM used for a given P (stats slab tiles = P / BM)
 void pw_gemm_force_bk(int bk);  // tuning knob (0 = automatic)
@@ -113,7 +116,6 @@ struct IrbxArgs {
   int ablate;                                    // timing ablations (results wrong when non-zero; 0 in production)
 };
 void irbx_ablate(int v);
-void irbx_ws(int v);  // 1 (default): the wave-specialised expand_dw kernel
 void irbx_stamp(int v);
 hipError_t irbx_stamp_fetch(double* out4);
 bool irbx_supported(int dtype, int Cin, int c0, int Chid, int H, int W);
@@ -140,8 +142,6 @@ struct SeArgs {
   float* gate;                      // [B][C]
   int B, C, Cs;
 };
-bool se_fused_supported(const SeArgs& a);   // one-launch form for narrow blocks (se_fused_kernel)
-hipError_t launch_se_fused(int dtype, const SeArgs& a, hipStream_t s);
 hipError_t launch_se_fc1(int dtype, const SeArgs& a, hipStream_t s);
 hipError_t launch_se_fc2(int dtype, const SeArgs& a, hipStream_t s);
 

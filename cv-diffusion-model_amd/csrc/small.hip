@@ -206,72 +206,6 @@ __global__ void __launch_bounds__(256) se_fc2_kernel(const SeArgs a) {
   }
 }
 
-// The whole SE MLP of one image in ONE workgroup (pool partials -> mean -> fc1 + ReLU6 -> fc2 + sigmoid), for the
-// narrow blocks (C <= kSeFusedMaxC) where three dependent launches cost far more than their work: the FC weights
-// (<= 256 KB) are re-read by every image's workgroup, from L2.  Same reduction orders as the three-kernel chain, so
-// both give the same bits; an image's gate never depends on its batch mates.
-constexpr int kSeFusedMaxC = 512;
-template <typename T>
-__global__ void __launch_bounds__(256) se_fused_kernel(const SeArgs a) {
-  extern __shared__ float sm[];  // [C] mean, [Cs] hidden, [16][64] pool partials
-  float* smean = sm;
-  float* shid = sm + a.C;
-  float* part = shid + a.Cs;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int b = blockIdx.x;
-  const int ps = a.pool_stride ? a.pool_stride : a.C;
-  const int c4 = tid & 15, tg = tid >> 4;
-  for (int c0 = 0; c0 < a.C; c0 += 64) {
-    const int c = c0 + c4 * 4;
-    f32x4 s = {0.f, 0.f, 0.f, 0.f};
-    if (c < a.C) {
-      const float* p = a.pool + (size_t)b * a.ntiles * ps + c;
-      for (int t = tg; t < a.ntiles; t += 16) s += *reinterpret_cast<const f32x4*>(p + (size_t)t * ps);
-    }
-#pragma unroll
-    for (int e = 0; e < 4; ++e) part[tg * 64 + c4 * 4 + e] = s[e];
-    __syncthreads();
-    if (tid < 64 && c0 + tid < a.C) {
-      float t = 0.f;
-#pragma unroll
-      for (int g = 0; g < 16; ++g) t += part[g * 64 + tid];
-      t *= 1.f / (float)a.P;
-      smean[c0 + tid] = t;
-      a.mean[(size_t)b * a.C + c0 + tid] = t;
-    }
-    __syncthreads();
-  }
-  const T* w1 = reinterpret_cast<const T*>(a.w1);
-  for (int j = wave; j < a.Cs; j += 4) {
-    float v[kSeMaxB];
-    se_row_dots<T>(w1 + (size_t)j * a.C, smean, a.C, 1, lane, v);
-    if (lane == 0) {
-      const float hv = relu6f(v[0] + a.b1[j]);
-      shid[j] = hv;
-      a.hid[(size_t)b * a.Cs + j] = hv;
-    }
-  }
-  __syncthreads();
-  const T* w2 = reinterpret_cast<const T*>(a.w2);
-  for (int c = wave; c < a.C; c += 4) {
-    float v[kSeMaxB];
-    se_row_dots<T>(w2 + (size_t)c * a.Cs, shid, a.Cs, 1, lane, v);
-    if (lane == 0) a.gate[(size_t)b * a.C + c] = sigmoidf(v[0] + a.b2[c]);
-  }
-}
-bool se_fused_supported(const SeArgs& a) { return a.C <= kSeFusedMaxC && a.C % 4 == 0; }
-hipError_t launch_se_fused(int dtype, const SeArgs& a, hipStream_t s) {
-  note_kernel("se_fused_kernel");
-  const size_t lds = (size_t)(a.C + a.Cs + 16 * 64) * 4;
-  switch (dtype) {
-    case 0: hipLaunchKernelGGL(se_fused_kernel<float>, dim3(a.B), dim3(256), lds, s, a); break;
-    case 1: hipLaunchKernelGGL(se_fused_kernel<half_t>, dim3(a.B), dim3(256), lds, s, a); break;
-    case 2: hipLaunchKernelGGL(se_fused_kernel<bf16_t>, dim3(a.B), dim3(256), lds, s, a); break;
-    default: return hipErrorInvalidValue;
-  }
-  return hipGetLastError();
-}
-
 hipError_t launch_se_fc1(int dtype, const SeArgs& a, hipStream_t s) {
   note_kernel("se_pool_kernel+se_fc1_kernel+se_fc2_kernel");
   hipLaunchKernelGGL(se_pool_kernel, dim3((a.C + 63) / 64, a.B), dim3(256), 0, s, a);

@@ -221,6 +221,7 @@ int llie_dwconv3x3_tiles(int H, int W);
 int llie_copy_probe(const void* src, void* dst, int64_t bytes, llie_stream stream);
 int llie_tune(const char* knob, int value); /* tuning knobs for tools/gpu_tune.py: "gemm_bk" = 0 (auto) | 32 */
 int llie_debug_irbx_stamps(double* out4); /* diagnostic builds: see irbx.hip (STAMP) */
+int llie_debug_gemm_stamps(double* out3); /* diagnostic builds: see gemm.hip (STAMP) */
 
 /* Per-kernel-class timing with HIP events recorded on the launch stream (what bench.py's `roofline`
  * object is computed from).  llie_profile_begin arms recording for the classes in `class_mask`;

@@ -313,28 +313,6 @@ def test_recompute_form_whole_network_properties(dev):
         m.compute_dtype = None
 
 
-def test_fused_se_launch_equals_three_kernel_chain(dev):
-    """se_fused_kernel (pool + fc1 + fc2 of one image in one workgroup, narrow blocks) keeps the reduction orders of the
-    se_pool / se_fc1 / se_fc2 chain: block outputs are bit-identical with either."""
-    for cin, cout, hw, cd in [(32, 32, 32, None), (64, 128, 16, "fp16"), (128, 128, 16, "bf16")]:
-        name = f"sef_{cin}_{cout}"
-        blk = M.InvertedResidualBlock(cin, cout, 128)
-        blk.load_state_dict({k: synth_tensor(name + "." + k, tuple(v.shape)) for k, v in blk.state_dict().items()})
-        blk = blk.to(dev)
-        blk.compute_dtype = cd
-        x = synth_input(name + ".x", (3, cin, hw, hw), -2, 2).to(dev)
-        te = synth_input(name + ".temb", (3, 128), -1, 1).to(dev)
-        ys = []
-        try:
-            for v in (0, 1):
-                N.check(N.lib().llie_tune(b"se_fused", v))
-                with torch.no_grad():
-                    ys.append(blk(x, te))
-        finally:
-            N.check(N.lib().llie_tune(b"se_fused", 1))
-        assert torch.equal(ys[0], ys[1])
-
-
 # ------------------------------------------------------------------ weights changed behind PyTorch's back
 def test_inplace_data_writes_are_noticed(dev):
     """`p.data.copy_(...)` leaves `_version` and `data_ptr()` unchanged -- the reference's EMA swaps weights exactly this way

@@ -74,9 +74,8 @@ def net(cd="fp16", B=2):
 def perf(B=32, cd="fp16"):
     m = M.LowLightDiffusion(unet_variant="small", image_size=256, compute_dtype=cd).to(dev)
     low = torch.rand(B, 3, 256, 256, device=dev) * 2 - 1
-    for cfg in [("irbx", 0, {}), ("irbx", 1, {"irbx_ws": 0, "irbx_dbuf": 1, "irbx_tiles": 4}), ("irbx", 1, {"irbx_ws": 1, "irbx_tiles": 4}),
-                ("irbx", 1, {"irbx_ws": 1, "irbx_tiles": 2}), ("irbx", 1, {"irbx_ws": 1, "irbx_tiles": 8}), ("irbx", 0, {}),
-                ("irbx", 1, {"irbx_ws": 0, "irbx_dbuf": 1, "irbx_tiles": 4}), ("irbx", 1, {"irbx_ws": 1, "irbx_tiles": 4})]:
+    for cfg in [("irbx", 0, {}), ("irbx", 1, {"irbx_dbuf": 1, "irbx_tiles": 4}), ("irbx", 1, {"irbx_dbuf": 0, "irbx_tiles": 4}),
+                ("irbx", 0, {}), ("irbx", 1, {"irbx_dbuf": 1, "irbx_tiles": 4})]:
         N.check(L.llie_tune(cfg[0].encode(), cfg[1]))
         for k, v in cfg[2].items():
             N.check(L.llie_tune(k.encode(), v))

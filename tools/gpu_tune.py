@@ -102,6 +102,18 @@ if __name__ == "__main__":
                 row.append(f"{us:8.1f}us {tf:4.0f}TF {gbs:5.0f}GB/s")
             print(f"{name:28s} " + " ".join(f"{r:>26s}" for r in row), flush=True)
         print("sum(us):", {k: round(v, 1) for k, v in tot.items()})
+    if "gemm_stamp" in sys.argv[1:]:
+        out = (C.c_double * 3)()
+        for name, kind, P, segs, n in SHAPES:
+            L.llie_tune(b"gemm_stamp", 0)
+            us0, _, _ = gemm(kind, B * P, segs, n, P)
+            L.llie_tune(b"gemm_stamp", 1)
+            us, gbs, tf = gemm(kind, B * P, segs, n, P)
+            N.check(L.llie_debug_gemm_stamps(out))
+            tot = out[0] + out[1]
+            print(f"{name:28s} {us0:8.1f} us ({us:8.1f} stamped)  per wave: K loop {out[0]:9.0f} cyc ({100*out[0]/max(tot,1):4.1f}%)  epilogue {out[1]:9.0f} cyc "
+                  f"({100*out[1]/max(tot,1):4.1f}%)  waves {out[2]:.0f}", flush=True)
+        L.llie_tune(b"gemm_stamp", 0)
     if "dw" in sys.argv[1:]:
         for rep in range(2):
             for H, Cc in [(256, 128), (256, 384), (128, 768), (64, 1536)]:
