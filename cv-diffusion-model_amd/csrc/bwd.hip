@@ -68,7 +68,7 @@ __global__ void __launch_bounds__(256) bwd_mask_reduce_kernel(const BwdMaskArgs 
     red[rl][0][cv * VEC + e] = s1[e];
     red[rl][1][cv * VEC + e] = s2[e];
   }
-  __syncthreads();
+  wg_barrier();
   if (tid < 2 * CB) {
     const int j = tid / CB, cc = tid % CB;
     if (blockIdx.y * CB + cc < a.C) {
@@ -103,7 +103,7 @@ __global__ void __launch_bounds__(256) slab_reduce_kernel(const float* slab, flo
   }
 #pragma unroll
   for (int e = 0; e < 4; ++e) part[tg][c4 * 4 + e] = s[e];
-  __syncthreads();
+  wg_barrier();
   if (tid < 64 && blockIdx.x * 64 + tid < C) {
     float t = 0.f;
 #pragma unroll
@@ -152,7 +152,7 @@ __global__ void __launch_bounds__(256) gn_bwd_coef_kernel(const GnBwdArgs a) {
   t1 = wave_sum(t1);
   t2 = wave_sum(t2);
   if (lane == 0) { part[0][wave] = t1; part[1][wave] = t2; }
-  __syncthreads();
+  wg_barrier();
   const double n = (double)cg * (double)a.P;
   const float c1 = (float)(((part[0][0] + part[0][1]) + (part[0][2] + part[0][3])) / n);
   const float c2 = (float)(((part[1][0] + part[1][1]) + (part[1][2] + part[1][3])) / n);
@@ -375,7 +375,7 @@ __global__ void __launch_bounds__(8 * TX, 3) dw_wgrad_kernel(const DwWgradArgs a
     issue(r + 1);
     float gload[VEC];
     load_g(gy + 2, gload);
-    __syncthreads();
+    wg_barrier();
 #pragma unroll
     for (int kx = 0; kx < 3; ++kx) {
       float f[VEC];
@@ -397,10 +397,10 @@ __global__ void __launch_bounds__(8 * TX, 3) dw_wgrad_kernel(const DwWgradArgs a
   const size_t pbase = (((size_t)b * gridDim.x + blockIdx.x) * 9) * a.C + blockIdx.y * CC;
 #pragma unroll
   for (int t = 0; t < 9; ++t) {
-    __syncthreads();
+    wg_barrier();
 #pragma unroll
     for (int e = 0; e < VEC; ++e) red[xl][cl * VEC + e] = acc[t][e];
-    __syncthreads();
+    wg_barrier();
     if (tid < CC) {
       float v = 0.f;
       for (int q = 0; q < TX; ++q) v += red[q][tid];
@@ -460,7 +460,7 @@ __global__ void __launch_bounds__(256) linear_dx_kernel(const float* dy, int64_t
     for (int r = r0 + rg; r < r1; r += 4) acc += dyr[r] * (float)W[(size_t)r * Kc + k];
   }
   part[rg][kl] = acc;
-  __syncthreads();
+  wg_barrier();
   if (rg == 0 && k < Kc)
     dst[((size_t)blockIdx.z * B + b) * Kc + k] = (part[0][kl] + part[1][kl]) + (part[2][kl] + part[3][kl]);
 }
@@ -801,7 +801,7 @@ __global__ void __launch_bounds__(256) linattn_bwd_q_kernel(const AttnBwdArgs a)
     sraw[n][c] = q;
     sq[n][c] = phi_f(q);
   }
-  __syncthreads();
+  wg_barrier();
   const int n = tid >> 2, e0 = (tid & 3) * 8;
   {
     float num[8], den = 0.f, dsum = 0.f;
@@ -826,7 +826,7 @@ __global__ void __launch_bounds__(256) linattn_bwd_q_kernel(const AttnBwdArgs a)
     dsum += __shfl_xor(dsum, 2, 64);
     if ((tid & 3) == 0) sdd[n] = -dsum;
   }
-  __syncthreads();
+  wg_barrier();
   {  // dq for d in [e0, e0+8)
     T* dq = reinterpret_cast<T*>(a.dqkv) + ((size_t)b * a.N + n0 + n) * ld + h * 32 + e0;
     const float dd = sdd[n];
@@ -873,7 +873,7 @@ __global__ void __launch_bounds__(256) linattn_bwd_kv_kernel(const AttnBwdArgs a
     sk[n][c] = phi_f(k);
     sv[n][c] = (float)base[(size_t)n * ld + 2 * inner + c];
   }
-  __syncthreads();
+  wg_barrier();
   const int n = tid >> 2, e0 = (tid & 3) * 8;
   T* drow = reinterpret_cast<T*>(a.dqkv) + ((size_t)b * a.N + n0 + n) * ld + h * 32 + e0;
 #pragma unroll

@@ -85,6 +85,17 @@ __device__ __forceinline__ void fma_mix_hi(float& acc, uint32_t w2, uint32_t f2)
 }
 
 // ---------------------------------------------------------------------------------------------
+// Workgroup barrier that first drains this wave's outstanding LDS operations.  __syncthreads() alone is not enough on
+// gfx950: the target has back-off barriers, so hipcc does not place an s_waitcnt in front of s_barrier by itself, and its
+// memory model treats LDS as totally ordered across the waves of a workgroup -- a ds_write issued just before the
+// barrier may still be in flight when a wave on another SIMD reads the location right after it (seen as a rare
+// wrong pool partial in expand_dw_kernel).
+__device__ __forceinline__ void wg_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __syncthreads();
+}
+
+// ---------------------------------------------------------------------------------------------
 // Packed affine (+ clamp to [0, 1]) for operand prologues.  The kernels of this engine run out of VALU issue slots
 // before anything else (a wave64 instruction holds its SIMD for 4 cycles), so ReLU6 is carried as clamp01(z / 6) -- the
 // clamp is the FMA's free output modifier -- and the factor 6 is pushed through the linear operator that follows.

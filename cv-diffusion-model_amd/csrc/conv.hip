@@ -41,7 +41,7 @@ __global__ void __launch_bounds__(256) init_conv_kernel(const InitConvArgs a) {
     }
     patch[ci][py][px] = v;
   }
-  __syncthreads();
+  wg_barrier();
   const int py = tid >> 4, px = tid & 15;
   const float* __restrict__ w = a.w;
   T* out = reinterpret_cast<T*>(a.out) + (((size_t)b * a.H + y0 + py) * a.W + x0 + px) * a.Cout;
@@ -76,13 +76,13 @@ __global__ void __launch_bounds__(256) init_conv_kernel(const InitConvArgs a) {
           red[wave][1][o] = s2;
         }
       }
-      __syncthreads();
+      wg_barrier();
       if (tid < 64) {
         const int which = tid >> 5, o = tid & 31;
         const float t = red[0][which][o] + red[1][which][o] + red[2][which][o] + red[3][which][o];
         a.stats[((size_t)(b * ntiles + blockIdx.x) * 2 + which) * a.Cout + oc0 + o] = t;
       }
-      __syncthreads();
+      wg_barrier();
     }
   }
 }
@@ -120,7 +120,7 @@ __global__ void __launch_bounds__(256) init_conv_mfma_kernel(const InitConvArgs 
     }
     patch[i] = v;
   }
-  __syncthreads();
+  wg_barrier();
   const int r = lane & 31, h = lane >> 5;
   const T* wp = reinterpret_cast<const T*>(a.wp);
   T* out = reinterpret_cast<T*>(a.out) + (size_t)b * a.H * a.W * a.Cout;
@@ -177,13 +177,13 @@ __global__ void __launch_bounds__(256) init_conv_mfma_kernel(const InitConvArgs 
         red[wave][0][lane] = s1;
         red[wave][1][lane] = s2;
       }
-      __syncthreads();
+      wg_barrier();
       if (tid < 64) {
         const int which = tid >> 5, o = tid & 31;
         const float tt = red[0][which][o] + red[1][which][o] + red[2][which][o] + red[3][which][o];
         a.stats[((size_t)(b * ntiles + blockIdx.x) * 2 + which) * a.Cout + oc0 + o] = tt;
       }
-      __syncthreads();
+      wg_barrier();
     }
   }
 }
@@ -224,7 +224,7 @@ __global__ void __launch_bounds__(256) final_conv_kernel(const FinalConvArgs a) 
   const float* __restrict__ w = a.w;
   float acc[4] = {0.f, 0.f, 0.f, 0.f};
   for (int cc = 0; cc < a.C; cc += 32) {
-    if (cc) __syncthreads();
+    if (cc) wg_barrier();
     for (int i = tid; i < 18 * 18 * VPP; i += 256) {
       const int pix = i / VPP, cv = (i % VPP) * VEC;
       const int ppy = pix / 18, ppx = pix % 18;
@@ -244,7 +244,7 @@ __global__ void __launch_bounds__(256) final_conv_kernel(const FinalConvArgs a) 
 #pragma unroll
       for (int e = 0; e < VEC; ++e) patch[cv + e][ppy][ppx] = f[e];
     }
-    __syncthreads();
+    wg_barrier();
     for (int ci = 0; ci < 32; ++ci) {
 #pragma unroll
       for (int tap = 0; tap < 9; ++tap) {
@@ -290,7 +290,7 @@ __global__ void __launch_bounds__(256) final_conv_mfma_kernel(const FinalConvArg
   for (int e = 0; e < 8; ++e) zero[e] = (T)0.f;
 
   for (int cc = 0; cc < a.C; cc += 32) {
-    if (cc) __syncthreads();
+    if (cc) wg_barrier();
     // stage the activated 18x18x32 patch (GroupNorm affine + SiLU applied once per element); a thread's
     // 8-channel slice is loop invariant (256 % 4 == 0), so its affine pairs live in registers
     const int cv = (tid & 3) * 8;
@@ -314,7 +314,7 @@ __global__ void __launch_bounds__(256) final_conv_mfma_kernel(const FinalConvArg
       }
       *reinterpret_cast<vec_t*>(patch + pix * PIX + cv) = v;
     }
-    __syncthreads();
+    wg_barrier();
     // A operand: this lane's weight fragments (non-zero only for output channels r < 4)
     vec_t wf[18];
 #pragma unroll
@@ -567,7 +567,7 @@ __global__ void __launch_bounds__(WM* WN * 64) conv3x3_kernel(const Conv3Args a)
     }
     stage_w(0);
     prefetch_w(1, c0);
-    __syncthreads();  // patch and W tile of tap 0 visible
+    wg_barrier();  // patch and W tile of tap 0 visible
     if (PREF && c0 + 32 < a.Cin) issue_patch(c0 + 32);
     for (int tap = 0; tap < 9; ++tap) {
       const int toff = ((tap / 3) * PW + (tap % 3)) * PITCH;
@@ -592,7 +592,7 @@ __global__ void __launch_bounds__(WM* WN * 64) conv3x3_kernel(const Conv3Args a)
         stage_w((tap + 1) & 1);  // its last readers finished before the previous barrier
         if (tap + 2 < 9) prefetch_w(tap + 2, c0);
       }
-      __syncthreads();  // next W tile visible; everyone done with this one (and, after tap 8, with the patch)
+      wg_barrier();  // next W tile visible; everyone done with this one (and, after tap 8, with the patch)
     }
   }
 
@@ -611,7 +611,7 @@ __global__ void __launch_bounds__(WM* WN * 64) conv3x3_kernel(const Conv3Args a)
   T* outp = reinterpret_cast<T*>(a.out) + (size_t)b * Ho * Wo * a.Cout;
 #pragma unroll
   for (int pi = 0; pi < MI; ++pi) {
-    if (pi) __syncthreads();
+    if (pi) wg_barrier();
 #pragma unroll
     for (int j = 0; j < NI; ++j)
 #pragma unroll
@@ -620,7 +620,7 @@ __global__ void __launch_bounds__(WM* WN * 64) conv3x3_kernel(const Conv3Args a)
         const int col = (wn * NI + j) * 32 + (lane & 31);
         sC[row * CP + col] = acc[pi][j][r];
       }
-    __syncthreads();
+    wg_barrier();
     for (int srow = r0; srow < SROWS; srow += RPP) {
       const int row = ((srow >> 5) * MI + pi) * 32 + (srow & 31);  // pixel index inside the BM tile
       float v[VEC];
@@ -655,7 +655,7 @@ __global__ void __launch_bounds__(WM* WN * 64) conv3x3_kernel(const Conv3Args a)
         red[(wave * 2 + 1) * BN + cv * VEC + e] = s2[e];
       }
     }
-    __syncthreads();
+    wg_barrier();
     for (int i = tid; i < 2 * BN; i += NT) {
       const int which = i / BN, c = i % BN;
       float t = 0.f;

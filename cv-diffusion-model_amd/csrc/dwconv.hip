@@ -158,7 +158,7 @@ __device__ __forceinline__ void dw_body(const DwArgs& a, const int TYL, const in
       buf[(xl + 1) * 8 + cl] = row_ok ? ((dbg & 2) ? pre[j % 4] : activate(pre[j % 4])) : zero;
       if (is_halo) buf[hslot * 8 + cl] = (row_ok && hx_ok) ? activate(preh[j % 4]) : zero;
       issue(r + PF, pre[j % 4], preh[j % 4]);
-      __syncthreads();
+      wg_barrier();
       vec_t f[3];
 #pragma unroll
       for (int kx = 0; kx < 3; ++kx) f[kx] = buf[(xl + kx) * 8 + cl];
@@ -225,14 +225,14 @@ __device__ __forceinline__ void dw_body(const DwArgs& a, const int TYL, const in
   }
   // ---- SE pool partials, one per 8-row segment (layout independent of the strip height)
   if constexpr (BWD) {  // slab[b][tile][{sum dz, sum dz*bx}][C]
-    __syncthreads();
+    wg_barrier();
     const int ntiles = tiles_x * (a.H / kPoolSegRows);
     float* base = a.bslab + (size_t)b * ntiles * 2 * a.C + chunk_id * CC;
     pool_segments_store<CC, NT>(red, TYL / kPoolSegRows, tid, base, 2 * a.C, ty * (TYL / kPoolSegRows), tiles_x, tx);
     pool_segments_store<CC, NT>(red + 8 * (NT / 64) * CC, TYL / kPoolSegRows, tid, base + a.C, 2 * a.C,
                                 ty * (TYL / kPoolSegRows), tiles_x, tx);
   } else if (a.pool) {
-    __syncthreads();
+    wg_barrier();
     const int ntiles = tiles_x * (a.H / kPoolSegRows);
     pool_segments_store<CC, NT>(red, TYL / kPoolSegRows, tid, a.pool + (size_t)b * ntiles * a.C + chunk_id * CC, a.C,
                                 ty * (TYL / kPoolSegRows), tiles_x, tx);

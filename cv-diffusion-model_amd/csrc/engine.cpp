@@ -523,6 +523,7 @@ int build_module(llie_ctx* c) {
 // Recompute form (irbx.hip: statistics-only expand + tile-fused expand/depthwise): default for the
 // inference path of 2-byte engines wherever irbx_supported(); llie_tune("irbx", 0) restores the unfused pair.
 int g_use_irbx = getenv("LLIE_NO_IRBX") ? 0 : 1;
+int g_irbx_mask = 0x7;  // debug: which input widths may take the recompute form (bit 0: 32, bit 1: 64, bit 2: 96 channels)
 // Backward pass: run the weight-gradient kernels on a side stream next to the activation-gradient chain
 // (llie_tune("bwd_async", 0) puts everything back on the caller's stream).
 int g_bwd_async = 1;
@@ -620,7 +621,7 @@ struct Run {
     gn(x0, x1, w.n1g, w.n1b, nullptr, 0, as1, ab1, &rec.n1, s6 ? 1.f / 6.f : 0.f);
     // Recompute form (2-byte T, narrow inputs): a statistics-only expand pass, then the fused expand + depthwise kernel
     // rebuilds h1 on the fly, so the 4x-expanded tensor never touches HBM (irbx.hip).
-    const bool fusedx = !tape && g_use_irbx && w.hid == w.hid_r && w.cin == w.cin_r &&
+    const bool fusedx = !tape && g_use_irbx && w.hid == w.hid_r && w.cin == w.cin_r && ((g_irbx_mask >> (w.cin / 32 - 1)) & 1) &&
                         irbx_supported(dt, w.cin, x0.C, w.hid, H, W);
     // K1: expand with norm1 + ReLU6 prologue
     Tens h1;
@@ -2090,6 +2091,7 @@ int llie_tune(const char* knob, int value) {
   if (!strcmp(knob, "irbx_dbuf")) { irbx_tune(value, 0); return LLIE_OK; }
   if (!strcmp(knob, "irbx_tiles")) { irbx_tune(-1, value); return LLIE_OK; }
   if (!strcmp(knob, "irbx_stamp")) { irbx_stamp(value); return LLIE_OK; }
+  if (!strcmp(knob, "irbx_mask")) { g_irbx_mask = value; return LLIE_OK; }
   if (!strcmp(knob, "irbx_ablate")) { irbx_ablate(value); return LLIE_OK; }
   if (!strcmp(knob, "gemm_stamp")) { pw_gemm_stamp(value); return LLIE_OK; }
   if (!strcmp(knob, "gemm_ablate")) { pw_gemm_debug(value); return LLIE_OK; }

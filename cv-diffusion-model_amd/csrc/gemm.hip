@@ -157,7 +157,7 @@ __global__ void __launch_bounds__(WM* WN * 64) pw_gemm_kernel(const GemmArgs g) 
   prefetch(0);
   for (int c = 0; c < nchunks; ++c) {
     if (!(g.dbg & 2) || c == 0) stage();  // dbg bit 1: timing ablation (no re-staging)
-    __syncthreads();
+    wg_barrier();
     if (c + 1 < nchunks && !(g.dbg & 1)) prefetch((c + 1) * BK);  // dbg bit 0: timing ablation (stale tiles)
     const int lr = lane & 31, lk = (lane >> 5) * 16;
 #pragma unroll
@@ -180,7 +180,7 @@ __global__ void __launch_bounds__(WM* WN * 64) pw_gemm_kernel(const GemmArgs g) 
 #pragma unroll
         for (int j = 0; j < NI; ++j) Mfma<T>::chunk(fa[i], fb[j], acc[i][j]);
     }
-    __syncthreads();
+    wg_barrier();
   }
 
   if constexpr (STAMP) t_loop = __builtin_amdgcn_s_memtime();
@@ -209,7 +209,7 @@ __global__ void __launch_bounds__(WM* WN * 64) pw_gemm_kernel(const GemmArgs g) 
   const T* dotp = reinterpret_cast<const T*>(g.dot);
 #pragma unroll
   for (int pi = 0; pi < MI; ++pi) {
-    if (pi) __syncthreads();  // previous pass fully read
+    if (pi) wg_barrier();  // previous pass fully read
 #pragma unroll
     for (int j = 0; j < NI; ++j)
 #pragma unroll
@@ -218,7 +218,7 @@ __global__ void __launch_bounds__(WM* WN * 64) pw_gemm_kernel(const GemmArgs g) 
         const int col = (wn * NI + j) * 32 + (lane & 31);
         sC[row * CP + col] = acc[pi][j][r];
       }
-    __syncthreads();
+    wg_barrier();
 #pragma unroll
     for (int it = 0; it < (SROWS + RPP - 1) / RPP; ++it) {
       const int srow = r0 + it * RPP;
@@ -273,7 +273,7 @@ __global__ void __launch_bounds__(WM* WN * 64) pw_gemm_kernel(const GemmArgs g) 
           s1[q][e] += __shfl_xor(s1[q][e], o, 64);
           s2[q][e] += __shfl_xor(s2[q][e], o, 64);
         }
-      if (q) __syncthreads();
+      if (q) wg_barrier();
       if (lane < VR) {
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
@@ -281,7 +281,7 @@ __global__ void __launch_bounds__(WM* WN * 64) pw_gemm_kernel(const GemmArgs g) 
           red[(wave * 2 + 1) * BN + cv * VEC + e] = s2[q][e];
         }
       }
-      __syncthreads();
+      wg_barrier();
       const int tile = (m0 % g.P) / G + q;
       for (int i = tid; i < 2 * BN; i += NT) {
         const int which = i / BN, c = i % BN;

@@ -108,7 +108,7 @@ __global__ void __launch_bounds__(256, 2) expand_stats_kernel(const IrbxArgs a, 
     }
   };
   load(0);
-  __syncthreads();  // aff1 staged
+  wg_barrier();  // aff1 staged
   for (int step = 0; step < nsteps; ++step) {
     unsigned char* buf = sA[step & 1];
 #pragma unroll
@@ -118,7 +118,7 @@ __global__ void __launch_bounds__(256, 2) expand_stats_kernel(const IrbxArgs a, 
       *reinterpret_cast<vec_t*>(buf + (v / (2 * KS)) * XP + k * 2) = activate8<T>(raw[j], &aff1[0][k], &aff1[1][k]);
     }
     if (step + 1 < nsteps) load(step + 1);
-    __syncthreads();  // tile `step` complete; the other buffer (read during step - 1) is free for step + 1
+    wg_barrier();  // tile `step` complete; the other buffer (read during step - 1) is free for step + 1
 #pragma unroll
     for (int pb = 0; pb < 4; ++pb) {
       vec_t af[KS];
@@ -178,7 +178,7 @@ __global__ void __launch_bounds__(256, 2) expand_dw_kernel(const IrbxArgs a, con
   constexpr int XV = kXNPX * 2 * KS;                     // 16-byte vectors of one x halo tile
   constexpr int XPT = (XV + 255) / 256;                  // ... per thread
   constexpr int SH_BYTES = kXNPB * 32 * SHP;
-  constexpr bool PREF = KS <= 2;                         // next tile's x prefetched into registers (36 VGPRs at KS = 6: not worth a spill)
+  constexpr bool PREF = KS <= 2;        // next tile's x prefetched into registers (36 VGPRs at KS = 6: not worth a spill)
   typedef typename Elem<T>::vec_t vec_t;
   extern __shared__ __align__(16) unsigned char smem[];
   // [sH: (DBUF ? 2 : 1) x 192 x 128 B][sX: 192 x XP][wds: 9 x Chid T][aff2: 2 x Chid fp32][aff1: 2 x K fp32][red: 2 x 4 x 64 fp32]
@@ -263,7 +263,7 @@ __global__ void __launch_bounds__(256, 2) expand_dw_kernel(const IrbxArgs a, con
     for (int s = 0; s < KS; ++s) wf[s] = ld_vec<T>(w1 + (size_t)(chunk * 64 + chb * 32 + n) * K + 16 * s + 8 * h);
   };
   load_wf(chunk0);
-  __syncthreads();  // constants staged
+  wg_barrier();  // constants staged
 
   unsigned long long tk[4] = {0, 0, 0, 0}, t_prev = 0;
   auto stamp = [&](int slot) {
@@ -310,14 +310,14 @@ __global__ void __launch_bounds__(256, 2) expand_dw_kernel(const IrbxArgs a, con
       const int gy = y0 - 1 + q / kXH_W, gx = x0p - 1 + q % kXH_W;
       ok[i] = q < kXNPX && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
     }
-    __syncthreads();
+    wg_barrier();
     if (!DBUF) flush_pool();
     stamp(0);
 
     for (int chunk = chunk0; chunk < chunk1; ++chunk) {
       unsigned char* buf = sH + (DBUF ? par * SH_BYTES : 0);
       if (!DBUF && chunk > chunk0) {
-        __syncthreads();  // previous depthwise phase done with sH
+        wg_barrier();  // previous depthwise phase done with sH
         flush_pool();
       }
       // ---- MFMA: h1^T block (32 channels x 32 pixels) x 3 pixel blocks
@@ -382,7 +382,7 @@ __global__ void __launch_bounds__(256, 2) expand_dw_kernel(const IrbxArgs a, con
         *reinterpret_cast<u32x4*>(buf + q * SHP + (chb * 4 + 2 * h + 1) * 16) = hi2;
       }
       stamp(1);
-      __syncthreads();
+      wg_barrier();
       if (DBUF) flush_pool();
       stamp(2);
       // ---- depthwise 3x3 on the MFMA pipe.  The VALU is what this kernel runs out of (a wave64 instruction costs a SIMD
@@ -522,7 +522,7 @@ __global__ void __launch_bounds__(256, 2) expand_dw_kernel(const IrbxArgs a, con
     }
   }
   if (a.pool) {
-    __syncthreads();
+    wg_barrier();
     flush_pool();
   }
 }

@@ -65,7 +65,7 @@ __global__ void __launch_bounds__(256) gn_finalize_kernel(const GnFinalizeArgs a
     part[0][wave] = s1;
     part[1][wave] = s2;
   }
-  __syncthreads();
+  wg_barrier();
   s1 = (part[0][0] + part[0][1]) + (part[0][2] + part[0][3]);
   s2 = (part[1][0] + part[1][1]) + (part[1][2] + part[1][3]);
   const double n = (double)cg * (double)a.P;
@@ -128,7 +128,7 @@ __global__ void __launch_bounds__(256) se_pool_kernel(const SeArgs a) {
   }
 #pragma unroll
   for (int e = 0; e < 4; ++e) part[tg][c4 * 4 + e] = s[e];
-  __syncthreads();
+  wg_barrier();
   if (tid < 64 && blockIdx.x * 64 + tid < a.C) {
     float t = 0.f;
 #pragma unroll
@@ -174,7 +174,7 @@ __global__ void __launch_bounds__(256) se_fc1_kernel(const SeArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b0 = blockIdx.y * kSeMaxB, nb = min(kSeMaxB, a.B - b0);
   for (int i = tid; i < nb * a.C; i += 256) smean[i] = a.mean[(size_t)b0 * a.C + i];
-  __syncthreads();
+  wg_barrier();
   const T* w1 = reinterpret_cast<const T*>(a.w1);
   for (int jj = wave; jj < kSeRows; jj += 4) {
     const int j = blockIdx.x * kSeRows + jj;
@@ -193,7 +193,7 @@ __global__ void __launch_bounds__(256) se_fc2_kernel(const SeArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b0 = blockIdx.y * kSeMaxB, nb = min(kSeMaxB, a.B - b0);
   for (int i = tid; i < nb * a.Cs; i += 256) shid[i] = a.hid[(size_t)b0 * a.Cs + i];
-  __syncthreads();
+  wg_barrier();
   const T* w2 = reinterpret_cast<const T*>(a.w2);
   for (int cc = wave; cc < kSeRows; cc += 4) {
     const int c = blockIdx.x * kSeRows + cc;
@@ -250,13 +250,13 @@ __global__ void __launch_bounds__(256) time_embed_kernel(const TimeArgs a) {
       a.emb_out[(size_t)r * a.dim + half + i] = emb[half + i];
     }
   }
-  __syncthreads();
+  wg_barrier();
   for (int j = tid; j < a.T; j += 256) {
     float acc = a.b1[j];
     for (int k = 0; k < a.dim; ++k) acc += a.w1[(size_t)j * a.dim + k] * emb[k];
     hid[j] = siluf(acc);
   }
-  __syncthreads();
+  wg_barrier();
   for (int j = tid; j < a.T; j += 256) {
     float acc = a.b3[j];
     for (int k = 0; k < a.T; ++k) acc += a.w3[(size_t)j * a.T + k] * hid[k];
@@ -276,7 +276,7 @@ __global__ void __launch_bounds__(256) film_kernel(const FilmArgs a) {
   const int tid = threadIdx.x;
   const int r0 = blockIdx.y * kSeMaxB, nr = min(kSeMaxB, a.rows - r0);
   for (int i = tid; i < nr * a.T; i += 256) st[i] = a.silu_temb[(size_t)r0 * a.T + i];
-  __syncthreads();
+  wg_barrier();
   const int sub = tid & 15;
   const int f = blockIdx.x * 16 + (tid >> 4);
   if (f >= a.F) return;  // whole 16-lane group exits together; no block-level sync follows
@@ -336,7 +336,7 @@ __global__ void __launch_bounds__(256) linattn_kv_kernel(const AttnArgs a) {
       sk[n][c] = phi((float)row[inner + h * 32 + c]);
       sv[n][c] = (float)row[2 * inner + h * 32 + c];
     }
-    __syncthreads();
+    wg_barrier();
 #pragma unroll 8
     for (int n = 0; n < CH; ++n) {
       const float kd = sk[n][d];
@@ -344,7 +344,7 @@ __global__ void __launch_bounds__(256) linattn_kv_kernel(const AttnArgs a) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) acc[q] += kd * sv[n][e0 + q];
     }
-    __syncthreads();
+    wg_barrier();
   }
   float* out = a.kv + ((size_t)(sp * a.B + b) * a.heads + h) * 32 * 33;
 #pragma unroll
@@ -372,7 +372,7 @@ __global__ void __launch_bounds__(256) linattn_out_kernel(const AttnArgs a) {
     const int n = i >> 5, c = i & 31;
     sq[n][c] = (n0 + n < a.N) ? phi((float)base[(size_t)(n0 + n) * ld + h * 32 + c]) : 0.f;
   }
-  __syncthreads();
+  wg_barrier();
   const int n = tid >> 2, e0 = (tid & 3) * 8;
   if (n0 + n >= a.N) return;
   float acc[8], den = 0.f;
@@ -437,7 +437,7 @@ __global__ void __launch_bounds__(256) affine_add_kernel(const AffineAddArgs a) 
   // thread owns column vectors cv = tid % 64 + k*64 ... handled by looping rows per wave:
   // wave w processes rows w, w+4, ...; lanes stride over the row's vectors.
   for (int i = tid; i < 2 * 4 * a.C; i += 256) red[i] = 0.f;
-  __syncthreads();
+  wg_barrier();
   for (int v0 = lane; v0 < vpr; v0 += 64) {
     float sc[VEC], sh[VEC], s1[VEC], s2[VEC];
 #pragma unroll
@@ -477,7 +477,7 @@ __global__ void __launch_bounds__(256) affine_add_kernel(const AffineAddArgs a) 
     }
   }
   if (a.stats) {
-    __syncthreads();
+    wg_barrier();
     const int ntiles = a.P / kAffineTileRows, tile = (m0 % a.P) / kAffineTileRows;
     for (int i = tid; i < 2 * a.C; i += 256) {
       const int which = i / a.C, c = i % a.C;
@@ -512,7 +512,7 @@ __global__ void __launch_bounds__(256) nchw_to_nhwc_kernel(const float* x, T* y,
     const int c = i >> 6, p = i & 63;
     sm[c * 65 + p] = x[((size_t)b * Csrc + coff + c0 + c) * P + p0 + p];
   }
-  __syncthreads();
+  wg_barrier();
   for (int i = tid; i < 32 * 64; i += 256) {
     const int p = i >> 5, c = i & 31;
     const T v = (T)sm[c * 65 + p];
@@ -520,7 +520,7 @@ __global__ void __launch_bounds__(256) nchw_to_nhwc_kernel(const float* x, T* y,
     sm[c * 65 + p] = (float)v;  // element owned by this thread in this phase: no race
   }
   if (stats) {
-    __syncthreads();
+    wg_barrier();
     const int ntiles = P / 64, tile = blockIdx.x;
     if (tid < 32) {
       float s1 = 0.f, s2 = 0.f;
@@ -543,7 +543,7 @@ __global__ void __launch_bounds__(256) nhwc_to_nchw_kernel(const T* x, float* y,
     const int p = i >> 5, c = i & 31;
     sm[c * 65 + p] = (float)x[((size_t)b * P + p0 + p) * C + c0 + c];
   }
-  __syncthreads();
+  wg_barrier();
   for (int i = tid; i < 32 * 64; i += 256) {
     const int c = i >> 6, p = i & 63;
     y[((size_t)b * Cdst + coff + c0 + c) * P + p0 + p] = sm[c * 65 + p];
@@ -655,7 +655,7 @@ __global__ void __launch_bounds__(256) params_hash_kernel(const LoadDesc* descs,
   for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
   __shared__ unsigned long long red[4];
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
-  __syncthreads();
+  wg_barrier();
   if (threadIdx.x == 0) partial[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
 __global__ void __launch_bounds__(256) hash_finalize_kernel(const unsigned long long* partial, int count, unsigned long long* state,
@@ -666,7 +666,7 @@ __global__ void __launch_bounds__(256) hash_finalize_kernel(const unsigned long 
   for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
   __shared__ unsigned long long red[4];
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
-  __syncthreads();
+  wg_barrier();
   if (threadIdx.x == 0) {
     const unsigned long long h = red[0] + red[1] + red[2] + red[3];
     state[1] = (force || h != state[0]) ? 1ull : 0ull;
@@ -934,12 +934,23 @@ hipError_t launch_add_noise(const float* x0, const float* noise, const int64_t* 
 }
 
 // HBM copy-bandwidth probe (bench.py `peak_measured`): 16 bytes per lane, grid-stride.
+// four 16-byte loads in flight per lane before the (non-temporal) stores: a workgroup streams 16 KB per iteration
 __global__ void __launch_bounds__(256) copy_probe_kernel(const u32x4* __restrict__ src, u32x4* __restrict__ dst, int64_t n) {
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) dst[i] = src[i];
+  const int64_t stride = (int64_t)gridDim.x * 1024;
+  int64_t i = (int64_t)blockIdx.x * 1024 + threadIdx.x;
+  for (; i + 768 < n; i += stride) {
+    u32x4 v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = __builtin_nontemporal_load(src + i + j * 256);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) __builtin_nontemporal_store(v[j], dst + i + j * 256);
+  }
+  for (int j = 0; j < 4; ++j)  // ragged end
+    if (i + j * 256 < n) dst[i + j * 256] = src[i + j * 256];
 }
 hipError_t launch_copy_probe(const void* src, void* dst, int64_t bytes, hipStream_t s) {
   if (bytes % 16) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(copy_probe_kernel, dim3(256 * 16), dim3(256), 0, s, reinterpret_cast<const u32x4*>(src),
+  hipLaunchKernelGGL(copy_probe_kernel, dim3(256 * 8), dim3(256), 0, s, reinterpret_cast<const u32x4*>(src),
                      reinterpret_cast<u32x4*>(dst), bytes / 16);
   return hipGetLastError();
 }

@@ -141,14 +141,14 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgradArgs a, int rows_
   };
   fetch(0);
   for (int mc = 0; mc < rows_per_split; mc += kWgRows) {
-    __syncthreads();  // previous chunk's operand reads are done
+    wg_barrier();  // previous chunk's operand reads are done
 #pragma unroll
     for (int ps = 0; ps < NP; ++ps) {
       const int r = ps * RPP + rl;
       st_vec<T>(sG + r * PITCH + cv, gv[ps]);
       st_vec<T>(sA + r * PITCH + cv, av[ps]);
     }
-    __syncthreads();
+    wg_barrier();
     if (mc + kWgRows < rows_per_split) fetch(mc + kWgRows);  // next chunk's global loads fly under the MFMAs
 #pragma unroll
     for (int ch = 0; ch < kWgRows / 32; ++ch) {

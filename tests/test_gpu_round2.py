@@ -313,6 +313,50 @@ def test_recompute_form_whole_network_properties(dev):
         m.compute_dtype = None
 
 
+def test_recompute_form_is_race_free_under_concurrency(dev):
+    """Two engines run `enhance` on two streams at once (what the two half-batch graph branches do): every result must
+    equal the solo result bit for bit, for the double- and the single-buffered depthwise stage.  This is the screen that
+    caught a pool partial read before its LDS write had landed (common.h wg_barrier)."""
+    import ctypes as C
+    L = N.lib()
+    B = 8
+    spec = oracle.make_spec("small", 256)
+    sd = oracle.synth_state_dict(oracle.param_shapes(spec))
+    ms = []
+    for _ in range(2):
+        m = M.LowLightDiffusion(unet_variant="small", image_size=256, compute_dtype="fp16")
+        m.load_state_dict(sd)
+        ms.append(m.to(dev).eval())
+    g = torch.Generator().manual_seed(1)
+    ins = [((torch.rand(B, 3, 256, 256, generator=g) * 2 - 1).to(dev), torch.randn(4, B, 3, 256, 256, generator=g).to(dev)) for _ in range(2)]
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    try:
+        for dbuf in (1, 0):
+            N.check(L.llie_tune(b"irbx_dbuf", dbuf))
+            solo = [m.enhance(x, 4, noise=nz, return_intermediate=True).intermediate[-1].clone() for m, (x, nz) in zip(ms, ins)]
+            torch.cuda.synchronize()
+            for _ in range(4):
+                outs = []
+                for m, (x, nz), st in zip(ms, ins, streams):
+                    st.wait_stream(torch.cuda.current_stream())
+                    with torch.cuda.stream(st):
+                        outs.append(m.enhance(x, 4, noise=nz, return_intermediate=True).intermediate[-1])
+                torch.cuda.synchronize()
+                for o, s0 in zip(outs, solo):
+                    assert torch.equal(o, s0), f"dbuf={dbuf}"
+    finally:
+        N.check(L.llie_tune(b"irbx_dbuf", 1))
+
+
+def test_copy_probe_copies(dev):
+    """bench.py's bandwidth probe is a real copy (ragged sizes included)."""
+    for n16 in (1, 255, 1024, 4099, 256 * 8 * 1024 + 17):
+        src = torch.randint(-2**31, 2**31 - 1, (n16 * 4,), dtype=torch.int32, device=dev)
+        dst = torch.zeros_like(src)
+        N.check(N.lib().llie_copy_probe(src.data_ptr(), dst.data_ptr(), n16 * 16, torch.cuda.current_stream().cuda_stream))
+        assert torch.equal(src, dst)
+
+
 # ------------------------------------------------------------------ weights changed behind PyTorch's back
 def test_inplace_data_writes_are_noticed(dev):
     """`p.data.copy_(...)` leaves `_version` and `data_ptr()` unchanged -- the reference's EMA swaps weights exactly this way

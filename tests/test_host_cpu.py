@@ -316,3 +316,48 @@ def test_virtual_concat_block_needs_a_skip_conv():
     for cin, split in [(64, 32), (128, 32), (96, 33), (96, 96)]:
         with pytest.raises(ValueError):
             M.InvertedResidualBlock(cin, cin if split < cin and split % 32 == 0 else 32, 128, concat_split=split)
+
+
+def test_deepcopy_with_a_live_engine_handle():
+    """copy.deepcopy(model) is how the reference builds EMA / target networks (low_light_diffusion.py:312,
+    lcm_scheduler.py:353).  A model that already owns an engine handle (ctypes pointers) must copy: the copy starts
+    without handles and builds its own lazily."""
+    import copy
+    m = M.LowLightDiffusion(unet_variant="small", image_size=64)
+    h = native.Handle(m.unet._make_cfg(native.LLIE_F32))   # a context can be created without a device
+    m.unet._handles[(0, native.LLIE_F32)] = (h, None, None)
+    m._t_cache[("x",)] = torch.zeros(1)
+    c = copy.deepcopy(m)
+    assert c.unet._handles == {} and c.unet._workspaces == {} and c._t_cache == {}
+    assert len(m.unet._handles) == 1
+    assert all(torch.equal(a, b) and a.data_ptr() != b.data_ptr() for a, b in zip(m.parameters(), c.parameters()))
+    c.unet.mark_weights_dirty()
+    m.unet.mark_weights_dirty()
+    assert m.unet._handles[(0, native.LLIE_F32)][1] is None
+
+
+def test_scheduler_rejects_out_of_range_host_timesteps():
+    """lcm_scheduler.py:268 indexes alphas_cumprod with the timesteps: out of range raises.  The range check of
+    host-resident timesteps happens before anything touches a device."""
+    sch = M.LCMScheduler()
+    x = torch.zeros(2, 3, 4, 4)
+    for bad in ([0, 1000], [-1001, 5]):
+        with pytest.raises((IndexError, RuntimeError)) as ei:
+            sch.add_noise(x, x, torch.tensor(bad))
+        assert isinstance(ei.value, IndexError) or "HIP device" in str(ei.value)
+
+
+def test_bench_kernel_class_mapping():
+    """bench.py picks the class to bracket with events from the dominant kernel's NAME (round 1 mapped every GEMM to the
+    SE class through a 9-character prefix)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    assert b.kernel_class_of("pw_gemm_kernel<_Float16, 128, 128, 2, 2, 64>", native) == native.K_GEMM
+    assert b.kernel_class_of("expand_stats_kernel<_Float16, 2, 1>", native) == native.K_GEMM
+    assert b.kernel_class_of("dwconv3x3_kernel<_Float16, 32, 4>", native) == native.K_DW
+    assert b.kernel_class_of("expand_dw_kernel<_Float16, 2, 1>", native) == native.K_DW
+    assert b.kernel_class_of("conv3x3_kernel<_Float16, 1, 16, 128, 2, 2>", native) == native.K_CONV3
+    assert b.kernel_class_of("se_pool_kernel+se_fc1_kernel+se_fc2_kernel", native) == native.K_SE
+    assert b.kernel_class_of("gn_finalize_kernel", native) == native.K_OTHER

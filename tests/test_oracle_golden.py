@@ -208,6 +208,28 @@ def test_enhance_small256_samples(golden):
     check("enhanced", out["enhanced"])
 
 
+def test_large_variant(golden):
+    """BASELINE config 4's network: the reference's 4-step loop of large@64 and one forward of large@128
+    (tests/golden/large_kat.npz, tools/make_golden_large.py)."""
+    g = golden("large_kat.npz")
+    spec = oracle.make_spec("large", 64)
+    sd = oracle.synth_state_dict(oracle.param_shapes(spec))
+    low = synth_input("e2eL64.low", (1, 3, 64, 64), -1.0, -0.4)
+    torch.manual_seed(int(g["seed"][0]))
+    noise = [torch.randn(1, 3, 64, 64) for _ in range(4)]
+    out = oracle.enhance_ref(sd, spec, low, 4, noise)
+    for i in range(4):
+        assert max_abs(out["noise_pred"][i], g[f"noise_pred_{i}"]) < 1e-4 * max(1.0, np.abs(g[f"noise_pred_{i}"]).max())
+        assert max_abs(out["intermediate"][i], g[f"latents_{i}"]) < 1e-4 * max(1.0, np.abs(g[f"latents_{i}"]).max())
+    assert max_abs(out["enhanced"], g["enhanced"]) < 1e-4
+    spec128 = oracle.make_spec("large", 128)
+    sd128 = oracle.synth_state_dict(oracle.param_shapes(spec128))
+    x = synth_input("large128.x", (1, 6, 128, 128), -1.5, 1.5)
+    with torch.no_grad():
+        y = oracle.unet_forward(sd128, spec128, x, torch.from_numpy(g["unet128_t"]))
+    assert max_abs(y, g["unet128"]) < 5e-5 * max(1.0, np.abs(g["unet128"]).max())
+
+
 # ------------------------------------------------------------------ deployment loop (android_pipeline.py:191-277)
 def test_deploy_loop_restatement_vs_reference(golden):
     from oracle import scheduler_ref as S

@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""Where do bits change?  One B=32 fp16 small@256 enhance under every combination of (recompute kernels on/off, half-batch
+graph branches on/off), first call (eager) vs later calls (graph replay), against the irbx=0 / split=0 eager result."""
+import importlib
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+M = importlib.import_module("cv-diffusion-model_amd")
+N = importlib.import_module("cv-diffusion-model_amd._native")
+dev = torch.device("cuda:0")
+L = N.lib()
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+m = M.LowLightDiffusion(unet_variant="small", image_size=256, compute_dtype="fp16").to(dev)
+g = torch.Generator().manual_seed(1234)
+low = (torch.rand(B, 3, 256, 256, generator=g) * 2 - 1).to(dev)
+noise = torch.randn(4, B, 3, 256, 256, generator=g).to(dev)
+res = {}
+if len(sys.argv) > 2:  # bisect: split on, recompute kernels restricted to some input widths / variants
+    for mask, dbuf in [(1, 1), (1, 0), (2, 0), (4, 0), (3, 1), (7, 1)]:
+        N.check(L.llie_tune(b"irbx", 1)); N.check(L.llie_tune(b"enhance_split", 1))
+        N.check(L.llie_tune(b"irbx_mask", mask)); N.check(L.llie_tune(b"irbx_dbuf", dbuf))
+        outs = [m.enhance(low, 4, noise=noise, return_intermediate=True).intermediate[-1].clone() for _ in range(5)]
+        eq = [torch.equal(outs[0], o) for o in outs[1:]]
+        rows = sorted({r for o in outs[1:] for r in (outs[0] != o).flatten(1).any(1).nonzero().flatten().tolist()})
+        print(f"mask={mask} dbuf={dbuf}: eager==replay {eq}  differing rows {rows}", flush=True)
+    sys.exit(0)
+
+for irbx in (0, 1):
+    for split in (0, 1):
+        N.check(L.llie_tune(b"irbx", irbx))
+        N.check(L.llie_tune(b"enhance_split", split))
+        outs = [m.enhance(low, 4, noise=noise, return_intermediate=True).intermediate[-1].clone() for _ in range(4)]
+        res[(irbx, split)] = outs
+        print(f"irbx={irbx} split={split}: call1(eager)==call2(graph) {torch.equal(outs[0], outs[1])}  call2==call3 {torch.equal(outs[1], outs[2])} "
+              f" call3==call4 {torch.equal(outs[2], outs[3])}", flush=True)
+        if not torch.equal(outs[0], outs[1]):
+            d = (outs[0] != outs[1])
+            rows = d.flatten(1).any(1).nonzero().flatten().tolist()
+            print(f"   differing batch rows: {rows}  max abs diff {(outs[0] - outs[1]).abs().max().item():.3e}", flush=True)
+for irbx in (0, 1):
+    print(f"irbx={irbx}: split0 eager == split1 graph {torch.equal(res[(irbx, 0)][0], res[(irbx, 1)][1])}; split0 graph == split1 graph "
+          f"{torch.equal(res[(irbx, 0)][1], res[(irbx, 1)][1])}")
+# single forward repeatability through the eager path only
+N.check(L.llie_tune(b"irbx", 1))
+os.environ["X"] = "1"
+t = torch.full((B,), 499, device=dev, dtype=torch.long)
+x = torch.cat([noise[0], low], 1)
+e = [m.unet(x, t).clone() for _ in range(3)]
+print("unet forward x3 (eager) equal:", torch.equal(e[0], e[1]), torch.equal(e[1], e[2]))
