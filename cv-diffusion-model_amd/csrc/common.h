@@ -193,6 +193,24 @@ __device__ __forceinline__ void pool_segments_store(const float* red, int nseg, 
   }
 }
 
+// Order-independent accumulation of fp32 partial sums: each partial is rounded to a multiple of 1 / scale and added
+// as a 64-bit integer (memory-side atomic, nothing returned).  Integer adds commute, so the total is bitwise independent
+// of which workgroup arrives first -- the engine's float reductions never use float atomics.
+__device__ __forceinline__ void fixed_add(unsigned long long* dst, float v, float scale) {
+  atomicAdd(dst, (unsigned long long)__float2ll_rn(v * scale));
+}
+template <int CC, int NT>
+__device__ __forceinline__ void pool_segments_add(const float* red, int nseg, int tid, unsigned long long* tot /* + b*C + cbase */, float scale) {
+  constexpr int NW = NT / 64;
+  for (int i = tid; i < nseg * CC; i += NT) {
+    const int seg = i / CC, c = i % CC;
+    float t = 0.f;
+#pragma unroll
+    for (int wv = 0; wv < NW; ++wv) t += red[(seg * NW + wv) * CC + c];
+    fixed_add(tot + c, t, scale);  // one add per 8-row segment: the total does not depend on the strip height
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // MFMA wrappers.  One k-chunk = 32 K-values; lane half h = lane>>5 owns k in [16h, 16h+16) of the
 // chunk for BOTH operands (any k permutation is legal as long as A and B agree), so each lane reads
@@ -221,6 +239,12 @@ template <> struct Mfma<bf16_t> {
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[1], bv[1], acc, 0, 0, 0);
   }
 };
+// one 32x32x16 MFMA on 8 packed 2-byte values per lane
+template <typename T>
+__device__ __forceinline__ f32x16 mfma16(typename Elem<T>::vec_t a, typename Elem<T>::vec_t b, f32x16 c) {
+  if constexpr (std::is_same<T, half_t>::value) return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
 // C/D layout of every 32x32 MFMA (dtype independent): col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
 __device__ __forceinline__ int mfma_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
 

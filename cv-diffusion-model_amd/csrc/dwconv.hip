@@ -214,7 +214,7 @@ __device__ __forceinline__ void dw_body(const DwArgs& a, const int TYL, const in
           st_vec<T>(out + ((size_t)(y0 + r - 2) * a.W + x0 + xl) * a.C, ov);
 #pragma unroll
           for (int e = 0; e < VEC; ++e) psum[e] += (float)ov[e];
-          if (a.pool && ((r - 2) & 7) == 7)  // uniform: an 8-row pool segment is complete
+          if ((a.pool || a.pool_tot) && ((r - 2) & 7) == 7)  // uniform: an 8-row pool segment is complete
             pool_segment_flush<VEC>(psum, red + (((r - 2) >> 3) * (NT / 64) + (tid >> 6)) * CC, tid & 63);
         }
       }
@@ -231,6 +231,9 @@ __device__ __forceinline__ void dw_body(const DwArgs& a, const int TYL, const in
     pool_segments_store<CC, NT>(red, TYL / kPoolSegRows, tid, base, 2 * a.C, ty * (TYL / kPoolSegRows), tiles_x, tx);
     pool_segments_store<CC, NT>(red + 8 * (NT / 64) * CC, TYL / kPoolSegRows, tid, base + a.C, 2 * a.C,
                                 ty * (TYL / kPoolSegRows), tiles_x, tx);
+  } else if (a.pool_tot) {
+    wg_barrier();
+    pool_segments_add<CC, NT>(red, TYL / kPoolSegRows, tid, a.pool_tot + (size_t)b * a.C + chunk_id * CC, kPoolFixScale);
   } else if (a.pool) {
     wg_barrier();
     const int ntiles = tiles_x * (a.H / kPoolSegRows);

@@ -204,6 +204,7 @@ struct llie_ctx {
   // hipGraph cache of llie_enhance launch sequences (key -> executable graph)
   struct GraphEntry { bool seen = false; hipGraphExec_t exec = nullptr; hipGraph_t graph = nullptr; };
   std::map<std::string, GraphEntry> graphs;
+  std::map<std::pair<int, int64_t>, size_t> zneed;  // (batch, pixels) -> bytes of zero-initialised totals one forward takes (Run::zbegin)
   hipStream_t cap_stream = nullptr;  // side stream used only to record captures (the legacy null stream cannot capture)
   // backward pass: weight-gradient kernels run on this stream next to the activation-gradient chain (Back::fork/join)
   hipStream_t side_stream = nullptr;
@@ -523,6 +524,8 @@ int build_module(llie_ctx* c) {
 // Recompute form (irbx.hip: statistics-only expand + tile-fused expand/depthwise): default for the
 // inference path of 2-byte engines wherever irbx_supported(); llie_tune("irbx", 0) restores the unfused pair.
 int g_use_irbx = getenv("LLIE_NO_IRBX") ? 0 : 1;
+int g_ztot = 1;  // SE pool as fixed-point totals + fused gate kernel (llie_tune("ztot", 0): the slab + three launches, as in training)
+int g_skip_small = 0;  // timing ablation only (results are garbage): bit 0 no gn_finalize launches, bit 1 no SE launches
 int g_irbx_mask = 0x7;  // debug: which input widths may take the recompute form (bit 0: 32, bit 1: 64, bit 2: 96 channels)
 // Backward pass: run the weight-gradient kernels on a side stream next to the activation-gradient chain
 // (llie_tune("bwd_async", 0) puts everything back on the caller's stream).
@@ -549,6 +552,36 @@ struct Run {
   Tape* tape = nullptr;  // non-null: training forward -- nothing is released, every operator is recorded
   char tag[56] = "";     // label of the operator being launched (llie_profile_dump)
   void rel(size_t off) { if (!tape) ar->free(off); }
+  // Zero-initialised totals (inference): fixed-point accumulators that kernels add to with integer atomics (SE pool sums).
+  // One block of the arena per forward, cleared by a single memset node at its start and handed out by ztake() in
+  // launch order; its size comes from a counting dry run of the same forward (cached per batch and image size).
+  size_t zoff = 0, zcur = 0, zcap = 0;
+  bool zcount = false;
+  template <typename F> void zbegin(int64_t pixels, F&& forward_again) {
+    if (tape || zcount) return;
+    const auto key = std::make_pair(B, pixels);
+    auto it = c->zneed.find(key);
+    if (it == c->zneed.end()) {
+      Arena probe((size_t)1 << 46);
+      Run d{c, &probe, nullptr, nullptr, true, B, dt};
+      d.zcount = true;
+      forward_again(d);
+      it = c->zneed.emplace(key, d.zcur).first;
+    }
+    zcap = it->second;
+    if (!zcap) return;
+    zoff = ar->alloc(zcap);
+    // a kernel of ours, not hipMemsetAsync: as a memset node of the captured graph it stopped clearing the region once another
+    // engine context had run between two replays (ROCm 7.2; tests/test_gpu_round2.py::test_inplace_data_writes_are_noticed)
+    if (!dry) chk(launch_zero_fill(ws + zoff, (int64_t)zcap, s));
+  }
+  size_t ztake(size_t bytes) {
+    bytes = align_up(bytes, 256);
+    const size_t off = zoff + zcur;
+    zcur += bytes;
+    if (!zcount && zcur > zcap) chk(hipErrorOutOfMemory);
+    return off;
+  }
 
   template <typename T = void> T* wptr(size_t off) const { return reinterpret_cast<T*>(c->blob + off); }
   template <typename T = void> T* p(size_t off) const { return reinterpret_cast<T*>(ws + off); }
@@ -605,6 +638,7 @@ struct Run {
     a.film = film; a.film_stride = film_stride; a.eps = 1e-5f;
     a.as = p<float>(as); a.ab = p<float>(ab); a.B = B; a.post_scale = post_scale;
     if (tape && rec) { a.mean_out = p<float>(mo); a.rstd_out = p<float>(ro); }
+    if (g_skip_small & 1) return;
     timed(LLIE_K_OTHER, (int64_t)B * C * 8, [&] { return launch_gn_finalize(a, s); }, "gn_finalize_kernel");
   }
 
@@ -657,15 +691,22 @@ struct Run {
     // K2: depthwise with affine + ReLU6 prologue and SE pool partials
     const int dnt = fusedx ? irbx_pool_tiles(H, W) : dwconv_ntiles(H, W);
     const size_t h2 = ar->alloc((size_t)M * w.hid * es());
-    const size_t pool = ar->alloc((size_t)B * dnt * w.hid * 4);
+    // SE pool: inference adds fixed-point channel totals into the zeroed region (one gate kernel follows); training keeps
+    // the slab of tile partials (the backward pass and the 3-launch SE path read it)
+    const bool ztot = !tape && g_ztot && w.hid % 128 == 0;
+    const size_t pool = ztot ? 0 : ar->alloc((size_t)B * dnt * w.hid * 4);
+    const size_t ptot = ztot ? ztake((size_t)B * w.hid * 8) : 0;
     if (!dry) {
       if (fusedx) {
-        xa.as2 = p<float>(as2); xa.ab2 = p<float>(ab2); xa.out = p(h2); xa.pool = p<float>(pool);
+        xa.as2 = p<float>(as2); xa.ab2 = p<float>(ab2); xa.out = p(h2);
+        xa.pool = ztot ? nullptr : p<float>(pool);
+        xa.pool_tot = ztot ? p<unsigned long long>(ptot) : nullptr;
         timed(LLIE_K_DW, (int64_t)M * (w.cin + w.hid) * (int64_t)es(), [&] { return launch_expand_dw(dt, xa, s); });
       } else {
         DwArgs d{};
         d.in = p(h1.off); d.out = p(h2); d.as = p<float>(as2); d.ab = p<float>(ab2);
-        d.w = wptr<float>(w.w_dw); d.pool = p<float>(pool); d.B = B; d.H = H; d.W = W; d.C = w.hid; d.s6 = s6dw ? 1 : 0;
+        d.w = wptr<float>(w.w_dw); d.pool = ztot ? nullptr : p<float>(pool);
+        d.pool_tot = ztot ? p<unsigned long long>(ptot) : nullptr; d.B = B; d.H = H; d.W = W; d.C = w.hid; d.s6 = s6dw ? 1 : 0;
         timed(LLIE_K_DW, 2LL * M * w.hid * (int64_t)es(), [&] { return launch_dwconv3x3(dt, d, s); });
       }
     }
@@ -678,15 +719,19 @@ struct Run {
     const size_t semean = ar->alloc((size_t)B * w.hid * 4);
     if (!dry) {
       SeArgs e{};
-      e.pool = p<float>(pool); e.ntiles = dnt; e.P = P;
+      e.pool = ztot ? nullptr : p<float>(pool); e.ntiles = dnt; e.P = P;
       e.w1 = wptr(w.se_w1); e.b1 = wptr<float>(w.se_b1); e.w2 = wptr(w.se_w2); e.b2 = wptr<float>(w.se_b2);
       e.mean = p<float>(semean); e.hid = p<float>(sehid); e.gate = p<float>(gate); e.B = B; e.C = w.hid; e.Cs = w.sq;
-      timed(LLIE_K_SE, ((int64_t)B * dnt * w.hid * 4) + 2LL * w.hid * w.sq * (int64_t)es(), [&] {
+      if (ztot) e.tot = p<unsigned long long>(ptot);
+      if (ztot && w.hid <= 384) {
+        if (!(g_skip_small & 2)) timed(LLIE_K_SE, (int64_t)B * w.hid * 12 + 2LL * w.hid * w.sq * (int64_t)es(), [&] { return launch_se_gate(dt, e, s); });
+      } else if (!(g_skip_small & 2)) timed(LLIE_K_SE, ((int64_t)B * dnt * w.hid * 4) + 2LL * w.hid * w.sq * (int64_t)es(), [&] {
         hipError_t r1 = launch_se_fc1(dt, e, s);
         return r1 != hipSuccess ? r1 : launch_se_fc2(dt, e, s);
       });
     }
-    rel(pool); rel(sehid); rel(semean);
+    if (!ztot) rel(pool);
+    rel(sehid); rel(semean);
     // K3: project with SE gate prologue (+ skip conv as extra K segments, or identity residual)
     Tens y = new_tens(w.cout, H, W, P / BM, w.cout_r);
     if (!dry) {
@@ -826,6 +871,7 @@ struct Run {
     const llie_config& g = c->cfg;
     const int S = g.image_size, T = g.time_embed_dim, F = c->film_rows;
     const int rows = uniform_t ? 1 : B;
+    zbegin((int64_t)S * S, [&](Run& d) { d.unet(nullptr, nullptr, nullptr, uniform_t, nullptr); });
     const size_t temb = ar->alloc((size_t)rows * T * 4), stemb = ar->alloc((size_t)rows * T * 4);
     const size_t film = ar->alloc((size_t)rows * F * 4);
     if (!dry) {
@@ -902,6 +948,7 @@ struct Run {
     const llie_config& g = c->cfg;
     const int P = H * W;
     const int split = (g.kind == LLIE_IRB) ? g.base_channels : 0;  // IRB: optional virtual-concat split point
+    zbegin((int64_t)P, [&](Run& d) { d.module(nullptr, nullptr, nullptr, H, W); });
     Tens x0 = new_tens(split ? split : g.in_channels, H, W, P / 64);
     Tens x1;
     if (split) x1 = new_tens(g.in_channels - split, H, W, P / 64);
@@ -2087,6 +2134,9 @@ int llie_tune(const char* knob, int value) {
   if (!knob) return LLIE_ERR_ARG;
   ++g_tune_epoch;
   if (!strcmp(knob, "gemm_bk")) { pw_gemm_force_bk(value); return LLIE_OK; }
+  if (!strcmp(knob, "gemm_big")) { pw_gemm_big(value); return LLIE_OK; }
+  if (!strcmp(knob, "skip_small")) { g_skip_small = value; return LLIE_OK; }
+  if (!strcmp(knob, "ztot")) { g_ztot = value; return LLIE_OK; }
   if (!strcmp(knob, "irbx")) { g_use_irbx = value != 0; return LLIE_OK; }
   if (!strcmp(knob, "irbx_dbuf")) { irbx_tune(value, 0); return LLIE_OK; }
   if (!strcmp(knob, "irbx_tiles")) { irbx_tune(-1, value); return LLIE_OK; }

@@ -28,12 +28,6 @@ namespace llie {
 
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
-template <typename T>
-__device__ __forceinline__ f32x16 mfma16(typename Elem<T>::vec_t a, typename Elem<T>::vec_t b, f32x16 c) {
-  if constexpr (std::is_same<T, half_t>::value) return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
-  else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
-}
-
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float dot2_bf16(uint32_t a, uint32_t b, float c) {
   return __builtin_amdgcn_fdot2_f32_bf16(*reinterpret_cast<const bf16x2_t*>(&a), *reinterpret_cast<const bf16x2_t*>(&b), c, false);
@@ -274,6 +268,7 @@ __global__ void __launch_bounds__(256, 2) expand_dw_kernel(const IrbxArgs a, con
     }
   };
   stamp(-1);
+  const bool has_pool = a.pool != nullptr || a.pool_tot != nullptr;
   int par = 0;  // sH / red buffer parity (DBUF)
   int pend_tile = -1, pend_chunk = 0, pend_par = 0;  // pool partial waiting for its cross-wave sum
   auto flush_pool = [&]() {  // after a barrier that follows the depthwise phase which wrote red[pend_par]
@@ -281,7 +276,8 @@ __global__ void __launch_bounds__(256, 2) expand_dw_kernel(const IrbxArgs a, con
       const float* r = red + pend_par * 256;  // wave (chb, pxg) = chb + 2 pxg left its 32 channel sums at [wave * 64 + channel]
       const int cbb = tid >> 5, ci = tid & 31;
       const float t = r[cbb * 64 + ci] + r[(cbb + 2) * 64 + ci];
-      a.pool[((size_t)b * ntiles_img + pend_tile) * a.Chid + pend_chunk * 64 + tid] = t;
+      if (a.pool_tot) fixed_add(a.pool_tot + (size_t)b * a.Chid + pend_chunk * 64 + tid, t, kPoolFixScale);
+      else a.pool[((size_t)b * ntiles_img + pend_tile) * a.Chid + pend_chunk * 64 + tid] = t;
     }
     pend_tile = -1;
   };
@@ -469,7 +465,7 @@ __global__ void __launch_bounds__(256, 2) expand_dw_kernel(const IrbxArgs a, con
         }
         // SE pool partial of this (tile, chunk): the 16 channel values of a lane summed over the wave's 64 pixels -- the
         // two blocks in registers, then a halving butterfly over the 32 pixel lanes (lane n ends up with channel slot (n>>1)&15)
-        if (a.pool && !(ABL & 2)) {
+        if (has_pool && !(ABL & 2)) {
           float v[16];
 #pragma unroll
           for (int r = 0; r < 16; ++r) v[r] = dacc[0][r] + dacc[1][r];
@@ -521,7 +517,7 @@ __global__ void __launch_bounds__(256, 2) expand_dw_kernel(const IrbxArgs a, con
       for (int i = 0; i < 4; ++i) a.dbg[(wg * 4 + wave) * 4 + i] = tk[i];
     }
   }
-  if (a.pool) {
+  if (has_pool) {
     wg_barrier();
     flush_pool();
   }

@@ -58,6 +58,7 @@ hipError_t pw_gemm_stamp_fetch(double* out3);
 hipError_t launch_pw_gemm(int dtype, const GemmArgs& a, hipStream_t s);
 int pw_gemm_tile_rows(int P);  // BM used for a given P (stats slab tiles = P / BM)
 void pw_gemm_force_bk(int bk);  // tuning knob (0 = automatic)
+void pw_gemm_big(int v);        // tuning knob: bit 0 256x256 tiles, bit 1 256x128 tiles
 void pw_gemm_debug(int v);      // timing ablations; results are wrong when non-zero
 
 // GroupNorm statistics -> per-(image, channel) affine tables.
@@ -91,6 +92,7 @@ struct DwArgs {
   const float* as; const float* ab;  // [B][C]
   const float* w;
   float* pool;
+  unsigned long long* pool_tot;  // inference: [B][C] fixed-point (x 2^24) channel totals, added with integer atomics (no pool slab)
   int B, H, W, C;
   int no_act;        // 1: prologue is the affine alone (backward: dh2 = da3*gate + dmean/P), 0: affine + ReLU6
   int s6;            // 1 (2-byte T, forward): as / ab hold scale / 6 and shift / 6 (GnFinalizeArgs::post_scale); the
@@ -110,6 +112,7 @@ struct IrbxArgs {
   const float* as2; const float* ab2;            // [B][Chid]  GroupNorm-2 + FiLM affine (ReLU6 follows), undivided
   const float* wd;                               // [9][Chid] fp32 depthwise weights, tap-major
   void* out; float* pool;                        // expand_dw outputs
+  unsigned long long* pool_tot;                  // or: [B][Chid] fixed-point channel totals (see DwArgs::pool_tot)
   float* stats;                                  // expand_stats output
   int B, H, W, Chid;
   unsigned long long* dbg;                       // diagnostic builds only (irbx_stamp)
@@ -141,7 +144,10 @@ struct SeArgs {
   float* hid;                       // [B][Cs]
   float* gate;                      // [B][C]
   int B, C, Cs;
+  const unsigned long long* tot;    // launch_se_gate: [B][C] fixed-point pool totals (kPoolFixScale)
 };
+constexpr float kPoolFixScale = 16777216.f;  // 2^24: per-tile pool partials are rounded to 2^-24 before the integer add
+hipError_t launch_se_gate(int dtype, const SeArgs& a, hipStream_t s);  // mean -> fc1 -> ReLU6 -> fc2 -> sigmoid, one launch
 hipError_t launch_se_fc1(int dtype, const SeArgs& a, hipStream_t s);
 hipError_t launch_se_fc2(int dtype, const SeArgs& a, hipStream_t s);
 
@@ -328,6 +334,7 @@ struct GnApplyArgs {
 hipError_t launch_gn_bwd_apply(int dtype, const GnApplyArgs& a, hipStream_t s);
 hipError_t launch_add_into(int dtype, void* dst, const void* src, int64_t n, hipStream_t s);   // dst += src
 hipError_t launch_fill_zero(void* dst, int64_t bytes, hipStream_t s);
+hipError_t launch_zero_fill(void* dst, int64_t bytes, hipStream_t s);  // kernel, not a memset node
 
 // (4) weight gradient of a 1x1 / one tap of a 3x3 convolution (TN GEMM on MFMA, split over the rows):
 //   out[n*ldn + k*ldk + off] = sum_m g[m][n] * A'[src(m)][k],   A' = act(a*as + ab) per K-segment as in GemmArgs;

@@ -173,7 +173,12 @@ __global__ void __launch_bounds__(256) se_fc1_kernel(const SeArgs a) {
   extern __shared__ float smean[];  // [nb][C] means of this block's image chunk
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b0 = blockIdx.y * kSeMaxB, nb = min(kSeMaxB, a.B - b0);
-  for (int i = tid; i < nb * a.C; i += 256) smean[i] = a.mean[(size_t)b0 * a.C + i];
+  if (a.tot) {  // fixed-point channel totals straight from the depthwise kernel: no pool pass
+    const double inv = 1.0 / ((double)a.P * (double)kPoolFixScale);
+    for (int i = tid; i < nb * a.C; i += 256) smean[i] = (float)((double)(long long)a.tot[(size_t)b0 * a.C + i] * inv);
+  } else {
+    for (int i = tid; i < nb * a.C; i += 256) smean[i] = a.mean[(size_t)b0 * a.C + i];
+  }
   wg_barrier();
   const T* w1 = reinterpret_cast<const T*>(a.w1);
   for (int jj = wave; jj < kSeRows; jj += 4) {
@@ -206,9 +211,101 @@ __global__ void __launch_bounds__(256) se_fc2_kernel(const SeArgs a) {
   }
 }
 
+// Inference form of the whole SE branch in one launch.  The depthwise kernels leave fixed-point channel totals
+// (DwArgs::pool_tot) instead of a slab of tile partials, so the mean is one conversion per channel.  Grid (G, B): every
+// workgroup of an image redoes fc1 + ReLU6 (weights come from L2; a 16-lane group per hidden row, eight 16-byte loads in
+// flight per lane -- with one workgroup per image and dependent loads the big layers took 60-200 us of pure latency) and
+// then owns C / G channels of fc2 + sigmoid (a thread per channel).  Sums run in an order fixed by (C, Cs) alone.
+// Used up to 384 channels (7-14 us against 20-38 for the three launches below); beyond that one workgroup per image is
+// slower than the row-parallel pair se_fc1 / se_fc2 (which then read the totals too, without the pool pass).
+template <typename T>
+__global__ void __launch_bounds__(1024) se_gate_kernel(const SeArgs a) {
+  extern __shared__ float sm[];  // [C] means, [Cs] hidden
+  float* mean = sm;
+  float* hid = sm + a.C;
+  constexpr int VEC = Elem<T>::VEC;
+  typedef typename Elem<T>::vec_t vec_t;
+  const int b = blockIdx.y, tid = threadIdx.x;
+  const double inv = 1.0 / ((double)a.P * (double)kPoolFixScale);
+  for (int c = tid; c < a.C; c += 1024) mean[c] = (float)((double)(long long)a.tot[(size_t)b * a.C + c] * inv);
+  wg_barrier();
+  {  // fc1: row j by lane group (tid >> 4); lane gl takes vectors gl, gl + 16, ... of the row
+    const T* w1 = reinterpret_cast<const T*>(a.w1);
+    const int gi = tid >> 4, gl = tid & 15;
+    const int its = a.C / (16 * VEC);  // launcher: C % (16 VEC) == 0
+    for (int j = gi; j < a.Cs; j += 64) {
+      const T* wr = w1 + (size_t)j * a.C + gl * VEC;
+      float acc = 0.f;
+      for (int i0 = 0; i0 < its; i0 += 8) {
+        vec_t w[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          if (i0 + u < its) w[u] = ld_vec<T>(wr + (size_t)(i0 + u) * 16 * VEC);
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          if (i0 + u < its) {
+            float f[VEC];
+            vec_to_f32<T>(w[u], f);
+            const float* mv = mean + (i0 + u) * 16 * VEC + gl * VEC;
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) acc += f[e] * mv[e];
+          }
+      }
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+      if (gl == 0) hid[j] = relu6f(acc + a.b1[j]);
+    }
+  }
+  wg_barrier();
+  const T* w2 = reinterpret_cast<const T*>(a.w2);
+  const int cs = a.C / gridDim.x;
+  for (int cc = tid; cc < cs; cc += 1024) {
+    const int c = blockIdx.x * cs + cc;
+    const T* wr = w2 + (size_t)c * a.Cs;
+    float acc = 0.f;
+    if (a.Cs % VEC == 0) {
+      const int nv = a.Cs / VEC;
+      for (int i0 = 0; i0 < nv; i0 += 8) {
+        vec_t w[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          if (i0 + u < nv) w[u] = ld_vec<T>(wr + (i0 + u) * VEC);
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          if (i0 + u < nv) {
+            float f[VEC];
+            vec_to_f32<T>(w[u], f);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) acc += f[e] * hid[(i0 + u) * VEC + e];
+          }
+      }
+    } else {
+      for (int k = 0; k < a.Cs; ++k) acc += (float)wr[k] * hid[k];
+    }
+    a.gate[(size_t)b * a.C + c] = sigmoidf(acc + a.b2[c]);
+  }
+}
+hipError_t launch_se_gate(int dtype, const SeArgs& a, hipStream_t s) {
+  if (!a.tot || !a.gate || a.C <= 0 || a.Cs <= 0 || a.P <= 0) return hipErrorInvalidValue;
+  const int vec = dtype == 0 ? 4 : 8;
+  const size_t lds = (size_t)(a.C + a.Cs) * 4;
+  if (lds > 48 * 1024 || a.C % (16 * vec)) return hipErrorInvalidValue;
+  int G = a.C / 256;  // fc2 channels per workgroup
+  if (G < 1) G = 1;
+  while (a.C % G) --G;
+  note_kernel("se_gate_kernel");
+  switch (dtype) {
+    case 0: hipLaunchKernelGGL(se_gate_kernel<float>, dim3(G, a.B), dim3(1024), lds, s, a); break;
+    case 1: hipLaunchKernelGGL(se_gate_kernel<half_t>, dim3(G, a.B), dim3(1024), lds, s, a); break;
+    case 2: hipLaunchKernelGGL(se_gate_kernel<bf16_t>, dim3(G, a.B), dim3(1024), lds, s, a); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
 hipError_t launch_se_fc1(int dtype, const SeArgs& a, hipStream_t s) {
-  note_kernel("se_pool_kernel+se_fc1_kernel+se_fc2_kernel");
-  hipLaunchKernelGGL(se_pool_kernel, dim3((a.C + 63) / 64, a.B), dim3(256), 0, s, a);
+  note_kernel(a.tot ? "se_fc1_kernel+se_fc2_kernel" : "se_pool_kernel+se_fc1_kernel+se_fc2_kernel");
+  if (!a.tot) hipLaunchKernelGGL(se_pool_kernel, dim3((a.C + 63) / 64, a.B), dim3(256), 0, s, a);
   dim3 grid((a.Cs + kSeRows - 1) / kSeRows, (a.B + kSeMaxB - 1) / kSeMaxB);
   const size_t lds = (size_t)kSeMaxB * a.C * 4;
   switch (dtype) {
@@ -934,6 +1031,21 @@ hipError_t launch_add_noise(const float* x0, const float* noise, const int64_t* 
 }
 
 // HBM copy-bandwidth probe (bench.py `peak_measured`): 16 bytes per lane, grid-stride.
+// zero fill as a kernel of this library (16 bytes per lane): the totals region of a forward (Run::zbegin)
+__global__ void __launch_bounds__(256) zero_fill_kernel(u32x4* __restrict__ dst, int64_t n16) {
+  const u32x4 z = {0u, 0u, 0u, 0u};
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (int64_t)gridDim.x * 256) dst[i] = z;
+}
+hipError_t launch_zero_fill(void* dst, int64_t bytes, hipStream_t s) {
+  if (bytes % 16 || (reinterpret_cast<uintptr_t>(dst) & 15)) return hipErrorInvalidValue;
+  const int64_t n16 = bytes / 16;
+  int grid = (int)((n16 + 255) / 256);
+  if (grid > 1024) grid = 1024;
+  if (grid < 1) grid = 1;
+  hipLaunchKernelGGL(zero_fill_kernel, dim3(grid), dim3(256), 0, s, reinterpret_cast<u32x4*>(dst), n16);
+  return hipGetLastError();
+}
+
 // four 16-byte loads in flight per lane before the (non-temporal) stores: a workgroup streams 16 KB per iteration
 __global__ void __launch_bounds__(256) copy_probe_kernel(const u32x4* __restrict__ src, u32x4* __restrict__ dst, int64_t n) {
   const int64_t stride = (int64_t)gridDim.x * 1024;
