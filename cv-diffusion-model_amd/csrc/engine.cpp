@@ -14,6 +14,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <tuple>
 #include <string>
 #include <vector>
 
@@ -204,7 +205,7 @@ struct llie_ctx {
   // hipGraph cache of llie_enhance launch sequences (key -> executable graph)
   struct GraphEntry { bool seen = false; hipGraphExec_t exec = nullptr; hipGraph_t graph = nullptr; };
   std::map<std::string, GraphEntry> graphs;
-  std::map<std::pair<int, int64_t>, size_t> zneed;  // (batch, pixels) -> bytes of zero-initialised totals one forward takes (Run::zbegin)
+  std::map<std::tuple<int, int64_t, int>, size_t> zneed;  // (batch, pixels, knob epoch) -> bytes of zero-initialised totals one forward takes (Run::zbegin)
   hipStream_t cap_stream = nullptr;  // side stream used only to record captures (the legacy null stream cannot capture)
   // backward pass: weight-gradient kernels run on this stream next to the activation-gradient chain (Back::fork/join)
   hipStream_t side_stream = nullptr;
@@ -559,7 +560,7 @@ struct Run {
   bool zcount = false;
   template <typename F> void zbegin(int64_t pixels, F&& forward_again) {
     if (tape || zcount) return;
-    const auto key = std::make_pair(B, pixels);
+    const auto key = std::make_tuple(B, pixels, tune_epoch());
     auto it = c->zneed.find(key);
     if (it == c->zneed.end()) {
       Arena probe((size_t)1 << 46);

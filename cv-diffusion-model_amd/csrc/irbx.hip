@@ -271,13 +271,21 @@ __global__ void __launch_bounds__(256, 2) expand_dw_kernel(const IrbxArgs a, con
   const bool has_pool = a.pool != nullptr || a.pool_tot != nullptr;
   int par = 0;  // sH / red buffer parity (DBUF)
   int pend_tile = -1, pend_chunk = 0, pend_par = 0;  // pool partial waiting for its cross-wave sum
+  long long pacc[KS];  // threads 0..63: fixed-point pool totals of channel tid of chunk chunk0 + q (Chid / 64 = KS chunks at most)
+#pragma unroll
+  for (int q = 0; q < KS; ++q) pacc[q] = 0;
   auto flush_pool = [&]() {  // after a barrier that follows the depthwise phase which wrote red[pend_par]
     if (pend_tile >= 0 && tid < 64) {
       const float* r = red + pend_par * 256;  // wave (chb, pxg) = chb + 2 pxg left its 32 channel sums at [wave * 64 + channel]
       const int cbb = tid >> 5, ci = tid & 31;
       const float t = r[cbb * 64 + ci] + r[(cbb + 2) * 64 + ci];
-      if (a.pool_tot) fixed_add(a.pool_tot + (size_t)b * a.Chid + pend_chunk * 64 + tid, t, kPoolFixScale);
-      else a.pool[((size_t)b * ntiles_img + pend_tile) * a.Chid + pend_chunk * 64 + tid] = t;
+      if (a.pool_tot) {  // fixed-point, summed over this workgroup's tiles in registers: one global atomic per chunk at the end
+        const long long v = __float2ll_rn(t * kPoolFixScale);
+#pragma unroll
+        for (int q = 0; q < KS; ++q) pacc[q] += (pend_chunk - chunk0 == q) ? v : 0ll;
+      } else {
+        a.pool[((size_t)b * ntiles_img + pend_tile) * a.Chid + pend_chunk * 64 + tid] = t;
+      }
     }
     pend_tile = -1;
   };
@@ -520,6 +528,11 @@ __global__ void __launch_bounds__(256, 2) expand_dw_kernel(const IrbxArgs a, con
   if (has_pool) {
     wg_barrier();
     flush_pool();
+    if (a.pool_tot && tid < 64) {
+#pragma unroll
+      for (int q = 0; q < KS; ++q)
+        if (chunk0 + q < chunk1) atomicAdd(a.pool_tot + (size_t)b * a.Chid + (chunk0 + q) * 64 + tid, (unsigned long long)pacc[q]);
+    }
   }
 }
 

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Per-launch table of one UNet forward inside `enhance` (GPU box): every kernel launch of the last of 4 steps with its
-operator tag, device time (HIP events on the launch stream) and algorithmic GB/s.  Usage: gpu_layers.py [dtype] [B] [size] [variant]"""
+operator tag, device time (HIP events on the launch stream) and algorithmic GB/s.  Usage: gpu_layers.py [dtype] [B] [size] [variant] [knob=value ...]"""
 import importlib
 import os
 import sys
@@ -19,6 +19,10 @@ def main():
     size = int(sys.argv[3]) if len(sys.argv) > 3 else 256
     variant = sys.argv[4] if len(sys.argv) > 4 else "small"
     dev = torch.device("cuda:0")
+    for kv in sys.argv[5:]:  # engine knobs: name=value
+        k, v = kv.split("=")
+        N.check(N.lib().llie_tune(k.encode(), int(v)))
+        print(f"# knob {k}={v}")
     m = M.LowLightDiffusion(unet_variant=variant, image_size=size, compute_dtype=dtype).to(dev)
     low = torch.rand(B, 3, size, size, device=dev) * 2 - 1
     for _ in range(2):
@@ -48,6 +52,13 @@ def main():
         print(f"{tag:34s} {name[:58]:58s} {ms*1e3:9.1f} us {b/1e6:9.1f} MB {b/(ms*1e-3)/1e9 if ms else 0:8.0f} GB/s")
         bytag[tag] = bytag.get(tag, 0.0) + ms
     print(f"# total {tot:.3f} ms / forward")
+    bykern = {}
+    for cls, name, tag, ms, b in acc:
+        k = (tag.split(" hid=")[0] if tag.startswith("irb") else tag) + " | " + name[:40]
+        bykern[k] = bykern.get(k, 0.0) + ms / reps
+    print("# per (operator, kernel):")
+    for k, ms in bykern.items():
+        print(f"#K  {k:80s} {ms*1e3:9.1f} us")
     print("# per operator:")
     for tag, ms in bytag.items():
         print(f"#   {tag:34s} {ms*1e3:9.1f} us")
