@@ -325,183 +325,6 @@ __global__ void __launch_bounds__(WM* WN * 64) pw_gemm_kernel(const GemmArgs g) 
   }
 }
 
-// ---------------------------------------------------------------------------------------------
-// 256 x 256 x 64 tiles for the matrix-bound shapes (expansions onto >= 512 channels, the decoder's concatenated inputs).
-// The kernel above keeps three workgroups of 64 x 64 wave tiles on a CU and leaves the matrix pipe ~18 % busy there: every
-// MFMA needs a fresh 16-byte LDS operand per lane, and stage -> barrier -> multiply -> barrier never overlaps inside a
-// workgroup.  Here one workgroup owns the CU: four waves of 128 x 128 (16 accumulator tiles = 256 AGPRs, half the LDS operand
-// traffic per MFMA), the LDS tile double-buffered (one barrier per 64-wide k-chunk), and the next chunk's staging
-// (operand prologue + ds_write) and the global loads of the one after are issued between the MFMAs of the running chunk.
-// k order and MFMA sequence per accumulator are those of the kernel above: results are bit-identical.
-// CLAMP: every segment's prologue is clamp01(a * s + b) (ReLU6 / 6, ACT_RELU6_S6); otherwise a * s + b, with s = 1, b = -0
-// for segments that have no tables (exact identity, keeps the loop free of branches).
-__device__ const float kIdentScale[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
-__device__ const float kIdentShift[8] = {-0.f, -0.f, -0.f, -0.f, -0.f, -0.f, -0.f, -0.f};
-
-// ABL (diagnostic builds, llie_tune("gemm_ablate")): 1 no MFMAs, 2 no global loads in the loop, 4 no staging in the loop, 8 no epilogue.
-template <typename T, bool CLAMP, bool STAMP = false, int ABL = 0>
-__global__ void __launch_bounds__(256, 1) pw_gemm256_kernel(const GemmArgs g) {
-  static_assert(sizeof(T) == 2, "2-byte operands only");
-  unsigned long long t_start = 0, t_loop = 0;
-  if constexpr (STAMP) t_start = __builtin_amdgcn_s_memtime();
-  constexpr int BM = 256, BN = 256, BK = 64, NT = 256, VEC = 8, PITCH = BK + VEC;
-  constexpr int MI = 4, NI = 4, WN = 2;
-  constexpr int TILE = (BM + BN) * PITCH;  // elements per LDS buffer: A rows then W rows
-  typedef typename Elem<T>::vec_t vec_t;
-
-  extern __shared__ __align__(16) unsigned char smem[];
-  T* sbuf = reinterpret_cast<T*>(smem);
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave / WN, wn = wave % WN;
-  const int nb = g.N / BN, mtiles = g.M / BM;
-  // blockIdx -> tile.  Workgroups are dealt round-robin to the 8 XCDs (one L2 each): keep all N tiles of an M tile, and
-  // runs of M tiles, on one XCD so that the A tile is fetched into one L2 only.
-  int mt, ntile;
-  if (mtiles % 8 == 0) {
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    mt = (slot / nb) * 8 + xcd;
-    ntile = slot % nb;
-  } else {
-    mt = blockIdx.x / nb;
-    ntile = blockIdx.x % nb;
-  }
-  const int m0 = mt * BM, n0 = ntile * BN;
-  const int img = m0 / g.P;
-  // staging geometry: 16-byte vector i of this thread = row (tid >> 3) + 32 i, k offset (tid & 7) * 8 of the chunk
-  const int srow = tid >> 3, kv = (tid & 7) * VEC;
-
-  f32x16 acc[MI][NI];
-#pragma unroll
-  for (int i = 0; i < MI; ++i)
-#pragma unroll
-    for (int j = 0; j < NI; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  vec_t ra[8], rb[8];
-  f32x4 rs[2], rt[2];
-  const int koff1 = g.seg[0].ch, koff2 = g.seg[0].ch + g.seg[1].ch;
-  // global addresses as (uniform 64-bit base) + (32-bit lane offset): the loads take the base in SGPRs
-  const unsigned char* wbase = reinterpret_cast<const unsigned char*>(g.w) + (size_t)n0 * g.K * 2;
-  const uint32_t wvoff = (uint32_t)(srow * g.K + kv) * 2u;
-  const size_t wstep = (size_t)32 * g.K * 2;
-
-  // chunk k0 -> (ra, rb, rs, rt); `part` 0..3 issues a quarter of it (spread over MFMA slots), -1 all
-  auto prefetch = [&](int k0, int part) {
-    const int s = (g.nseg > 1 && k0 >= koff1) + (g.nseg > 2 && k0 >= koff2);
-    const int cl = k0 - (s == 0 ? 0 : (s == 1 ? koff1 : koff2));
-    const void* ptr = s == 0 ? g.seg[0].ptr : (s == 1 ? g.seg[1].ptr : g.seg[2].ptr);
-    const int ch = s == 0 ? g.seg[0].ch : (s == 1 ? g.seg[1].ch : g.seg[2].ch);
-    const float* as = s == 0 ? g.seg[0].as : (s == 1 ? g.seg[1].as : g.seg[2].as);
-    const float* ab = s == 0 ? g.seg[0].ab : (s == 1 ? g.seg[1].ab : g.seg[2].ab);
-    const int ld = s == 0 ? g.seg[0].aff_ld : (s == 1 ? g.seg[1].aff_ld : g.seg[2].aff_ld);
-    const unsigned char* abase = reinterpret_cast<const unsigned char*>(ptr) + ((size_t)m0 * ch + cl) * 2;
-    const uint32_t avoff = (uint32_t)(srow * ch + kv) * 2u;
-    const size_t astep = (size_t)32 * ch * 2;
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-      if (part < 0 || (i >> 1) == part) ra[i] = *reinterpret_cast<const vec_t*>(abase + i * astep + avoff);
-    if (part < 0 || part == 0) {
-      const float* ps = as ? as + (size_t)img * ld + cl : kIdentScale - kv;
-      const float* pt = (as && ab) ? ab + (size_t)img * ld + cl : kIdentShift - kv;
-      rs[0] = *reinterpret_cast<const f32x4*>(ps + kv);
-      rs[1] = *reinterpret_cast<const f32x4*>(ps + kv + 4);
-      rt[0] = *reinterpret_cast<const f32x4*>(pt + kv);
-      rt[1] = *reinterpret_cast<const f32x4*>(pt + kv + 4);
-    }
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-      if (part < 0 || (i >> 1) == part) rb[i] = *reinterpret_cast<const vec_t*>(wbase + (size_t)k0 * 2 + i * wstep + wvoff);
-  };
-  // LDS byte addresses (buffer p at p * TILE * 2): staging rows and MFMA fragments
-  const int lr = lane & 31, lk = (lane >> 5) * 16;
-  const uint32_t st_off = (uint32_t)(srow * PITCH + kv) * 2u;
-  const uint32_t fa_off = (uint32_t)((wm * 128 + lr) * PITCH + lk) * 2u;
-  const uint32_t fb_off = (uint32_t)(BM * PITCH + (wn * 128 + lr) * PITCH + lk) * 2u;
-  auto stage_a = [&](uint32_t nxt, int i) {
-    const u32x4 x = reinterpret_cast<const u32x4&>(ra[i]);
-    u32x4 o;
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-      o[q] = act_clamp01_pack<T, CLAMP>(x[q], rs[q >> 1][2 * (q & 1)], rs[q >> 1][2 * (q & 1) + 1], rt[q >> 1][2 * (q & 1)], rt[q >> 1][2 * (q & 1) + 1]);
-    *reinterpret_cast<u32x4*>(smem + nxt + st_off + i * 32 * PITCH * 2) = o;
-  };
-  auto stage_b = [&](uint32_t nxt, int i) {
-    *reinterpret_cast<vec_t*>(smem + nxt + st_off + (BM + i * 32) * PITCH * 2) = rb[i];
-  };
-
-  // MFMA step t = 0..3 of a chunk: k columns {32 (t >> 1) + 16 h + 8 (t & 1) ..+7} for lane half h (the order of the kernel above)
-  vec_t fa[2][MI], fb[2][NI];
-  auto load_frag = [&](uint32_t cur, int t, int r) {  // r = 0..7: A blocks then W blocks
-    const int ko = ((t >> 1) * 32 + (t & 1) * 8) * 2;
-    if (r < 4) fa[t & 1][r] = *reinterpret_cast<const vec_t*>(smem + cur + fa_off + r * 32 * PITCH * 2 + ko);
-    else fb[t & 1][r - 4] = *reinterpret_cast<const vec_t*>(smem + cur + fb_off + (r - 4) * 32 * PITCH * 2 + ko);
-  };
-  // One chunk = 4 steps x 16 MFMA slots on buffer `cur`.  A wave issues in order and an MFMA keeps the matrix pipe for 32
-  // cycles, so each slot has room for ~7 issue cycles of other work: the slots carry, in this fixed order (sched_barrier
-  // pins it), the next step's operand reads, then STAGE: the chunk held in registers -> prologue -> buffer `nxt`, then
-  // PREF: the registers refilled from chunk kpref.
-  auto chunk = [&](uint32_t cur, uint32_t nxt, int kpref, auto stage_tag, auto pref_tag) {
-    constexpr bool STAGE = decltype(stage_tag)::value, PREF = decltype(pref_tag)::value;
-#pragma unroll
-    for (int r = 0; r < 8; ++r) load_frag(cur, 0, r);
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-#pragma unroll
-      for (int k = 0; k < 16; ++k) {
-        __builtin_amdgcn_sched_barrier(0);
-        if constexpr (!(ABL & 1)) acc[k >> 2][k & 3] = mfma16<T>(fa[t & 1][k >> 2], fb[t & 1][k & 3], acc[k >> 2][k & 3]);
-        else asm volatile("" :: "v"(fa[t & 1][k >> 2]), "v"(fb[t & 1][k & 3]));
-        if (t < 3 && k < 8) load_frag(cur, t + 1, k);
-        if constexpr (STAGE && !(ABL & 4)) {
-          if (t < 2 && k >= 8 && (k & 1) == 0) stage_a(nxt, t * 4 + (k - 8) / 2);
-          if (t == 2 && k >= 8) stage_b(nxt, k - 8);
-        }
-        if constexpr (PREF && !(ABL & 2)) {
-          if (t == 3 && (k & 3) == 0) prefetch(kpref, k >> 2);
-        }
-      }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-  };
-  using Yes = std::true_type;
-  using No = std::false_type;
-
-  const int nchunks = g.K / BK;  // >= 2 (launcher)
-  constexpr uint32_t TB = TILE * 2;
-  prefetch(0, -1);
-#pragma unroll
-  for (int i = 0; i < 8; ++i) { stage_a(0, i); stage_b(0, i); }
-  prefetch(BK, -1);
-  wg_barrier();
-  int c = 0;
-  for (; c + 2 < nchunks; ++c) {  // steady state: multiply chunk c, stage c + 1, fetch c + 2
-    const uint32_t cur = (c & 1) ? TB : 0u;
-    chunk(cur, TB - cur, (c + 2) * BK, Yes{}, Yes{});
-    wg_barrier();
-  }
-  {
-    const uint32_t cur = (c & 1) ? TB : 0u;
-    chunk(cur, TB - cur, 0, Yes{}, No{});
-    wg_barrier();
-    chunk(TB - cur, 0u, 0, No{}, No{});
-    wg_barrier();
-  }
-
-  if constexpr (STAMP) t_loop = __builtin_amdgcn_s_memtime();
-  if constexpr (!(ABL & 8)) gemm_epilogue<T, BM, BN, 2, 2>(g, acc, smem, m0, n0, img);
-  else if (g.dbg == 12345) reinterpret_cast<float*>(g.out)[tid] = acc[0][0][0] + acc[3][3][15] + acc[1][2][7];
-  if constexpr (STAMP) {
-    if (g.stamps && (threadIdx.x & 63) == 0) {  // one (K loop, epilogue) pair per wave, no atomics: the stamped launch keeps its timing
-      const unsigned long long t_end = __builtin_amdgcn_s_memtime();
-      const size_t wv = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-      g.stamps[2 * wv] = t_loop - t_start;
-      g.stamps[2 * wv + 1] = t_end - t_loop;
-    }
-  }
-}
-
 static int g_gemm_stamp = 0;
 static unsigned long long* g_gemm_stamps = nullptr;
 static size_t g_gemm_stamp_waves = 0;
@@ -560,51 +383,11 @@ static hipError_t launch_cfg(const GemmArgs& a, hipStream_t s) {
   return hipGetLastError();
 }
 
-template <typename T, bool CLAMP>
-static hipError_t launch_256(const GemmArgs& a, hipStream_t s) {
-  constexpr size_t lds = (size_t)2 * 512 * 72 * 2;  // two (A + W) k-chunks; the epilogue's C tile (64 x 260 fp32 + sums) fits inside
-  static bool attr_done = false;
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pw_gemm256_kernel<T, CLAMP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    attr_done = true;
-  }
-  const unsigned grid = (unsigned)((a.M / 256) * (a.N / 256));
-  if (g_gemm_stamp) {
-    if (hipError_t e = stamp_buffer((size_t)grid * 4); e != hipSuccess) return e;
-    GemmArgs b = a;
-    b.stamps = g_gemm_stamps;
-    auto go = [&](auto kern) -> hipError_t {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      if (e != hipSuccess) return e;
-      hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, b);
-      return hipGetLastError();
-    };
-    if constexpr (std::is_same<T, half_t>::value && CLAMP) {
-      switch (a.dbg) {
-        case 1: return go(&pw_gemm256_kernel<T, CLAMP, true, 1>);
-        case 2: return go(&pw_gemm256_kernel<T, CLAMP, true, 2>);
-        case 4: return go(&pw_gemm256_kernel<T, CLAMP, true, 4>);
-        case 6: return go(&pw_gemm256_kernel<T, CLAMP, true, 6>);
-        case 8: return go(&pw_gemm256_kernel<T, CLAMP, true, 8>);
-        case 14: return go(&pw_gemm256_kernel<T, CLAMP, true, 14>);
-        case 15: return go(&pw_gemm256_kernel<T, CLAMP, true, 15>);
-      }
-    }
-    return go(&pw_gemm256_kernel<T, CLAMP, true>);
-  }
-  static const std::string name = std::string("pw_gemm256_kernel<") + TypeName<T>::value + ", " + (CLAMP ? "1" : "0") + ">";
-  note_kernel(name.c_str());
-  hipLaunchKernelGGL((pw_gemm256_kernel<T, CLAMP>), dim3(grid), dim3(256), lds, s, a);
-  return hipGetLastError();
-}
-
 int pw_gemm_tile_rows(int P) { return (P % 128 == 0) ? 128 : 64; }
 
 // tuning knobs for tools/gpu_tune.py (0 = automatic)
-static int g_force_bk = 0, g_gemm_big = 0;
+static int g_force_bk = 0;
 void pw_gemm_force_bk(int bk) { g_force_bk = bk; }
-void pw_gemm_big(int v) { g_gemm_big = v; }
 
 template <typename T>
 static hipError_t launch_t(const GemmArgs& a, hipStream_t s) {
@@ -613,22 +396,6 @@ static hipError_t launch_t(const GemmArgs& a, hipStream_t s) {
   bool k64 = sizeof(T) == 2;  // BK = 64 needs every K segment to be a multiple of 64 (2-byte T only)
   for (int i = 0; i < a.nseg; ++i) k64 = k64 && (a.seg[i].ch % 64 == 0);
   if (g_force_bk == 32) k64 = false;
-  if constexpr (sizeof(T) == 2) {
-    if (BM == 128 && a.P % 256 == 0 && a.N % 256 == 0 && k64 && a.K >= 128 && (g_gemm_big & 8)) {
-      bool s6 = true, plain = true;  // the prologue form is a compile-time property of the big-tile kernel
-      for (int i = 0; i < a.nseg; ++i) {
-        s6 = s6 && a.seg[i].act == ACT_RELU6_S6;
-        plain = plain && a.seg[i].act == ACT_NONE;
-      }
-      if (s6) return launch_256<T, true>(a, s);
-      if (plain) return launch_256<T, false>(a, s);
-    }
-    if (BM == 128 && a.P % 256 == 0 && k64 && g_gemm_big) {
-      if (a.N % 256 == 0 && (g_gemm_big & 1)) return launch_cfg<T, 256, 256, 2, 2, 64>(a, s);
-      if (a.N % 256 == 0 && (g_gemm_big & 4)) return launch_cfg<T, 256, 256, 2, 4, 64>(a, s);
-      if (a.N % 128 == 0 && (g_gemm_big & 2)) return launch_cfg<T, 256, 128, 2, 2, 64>(a, s);
-    }
-  }
   if (BM == 128) {
     if (BN == 128) return k64 ? launch_cfg<T, 128, 128, 2, 2, 64>(a, s) : launch_cfg<T, 128, 128, 2, 2, 32>(a, s);
     if (BN == 64) return k64 ? launch_cfg<T, 128, 64, 2, 2, 64>(a, s) : launch_cfg<T, 128, 64, 2, 2, 32>(a, s);

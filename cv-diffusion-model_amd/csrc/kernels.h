@@ -58,7 +58,6 @@ hipError_t pw_gemm_stamp_fetch(double* out3);
 hipError_t launch_pw_gemm(int dtype, const GemmArgs& a, hipStream_t s);
 int pw_gemm_tile_rows(int P);  // BM used for a given P (stats slab tiles = P / BM)
 void pw_gemm_force_bk(int bk);  // tuning knob (0 = automatic)
-void pw_gemm_big(int v);        // tuning knob: bit 0 256x256 tiles, bit 1 256x128 tiles
 void pw_gemm_debug(int v);      // timing ablations; results are wrong when non-zero
 
 // GroupNorm statistics -> per-(image, channel) affine tables.

@@ -58,7 +58,6 @@ def gemm(kind, M, segs, Nout, P, dtype=1, B=32, act=1):
     es = 2 if dtype else 4
     nbytes = (M * K + M * Nout * (2 if res is not None else 1)) * es
     flops = 2.0 * M * K * Nout
-    gemm.last = (out, stats)
     return us, nbytes / us / 1e3, flops / us / 1e6
 
 
@@ -115,23 +114,6 @@ if __name__ == "__main__":
             print(f"{name:28s} {us0:8.1f} us ({us:8.1f} stamped)  per wave: K loop {out[0]:9.0f} cyc ({100*out[0]/max(tot,1):4.1f}%)  epilogue {out[1]:9.0f} cyc "
                   f"({100*out[1]/max(tot,1):4.1f}%)  waves {out[2]:.0f}", flush=True)
         L.llie_tune(b"gemm_stamp", 0)
-    if "abl256" in sys.argv[1:]:  # cycle stamps + compile-time ablations of the 256x256 kernel (K1 shapes, fp16)
-        out = (C.c_double * 3)()
-        L.llie_tune(b"gemm_big", 8)
-        for name, kind, P, segs, n in SHAPES:
-            if n % 256 or kind != "k1" or sum(segs) < 128:
-                continue
-            L.llie_tune(b"gemm_stamp", 0); L.llie_tune(b"gemm_ablate", 0)
-            us0, _, tf0 = gemm(kind, B * P, segs, n, P, act=3)
-            L.llie_tune(b"gemm_stamp", 1)
-            row = [f"{name:24s} prod {us0:6.1f}us {tf0:4.0f}TF |"]
-            for abl in (0, 1, 2, 4, 6, 8, 14, 15):
-                L.llie_tune(b"gemm_ablate", abl)
-                us, _, _ = gemm(kind, B * P, segs, n, P, act=3)
-                N.check(L.llie_debug_gemm_stamps(out))
-                row.append(f"abl{abl}: {us:6.1f}us loop {out[0]/1e3:6.1f}k epi {out[1]/1e3:5.1f}k |")
-            print(" ".join(row), flush=True)
-        L.llie_tune(b"gemm_stamp", 0); L.llie_tune(b"gemm_ablate", 0); L.llie_tune(b"gemm_big", 0)
     if "xcd" in sys.argv[1:]:  # XCD-aware tile order of the production kernel (gemm_ablate bit 4)
         for name, kind, P, segs, n in SHAPES:
             row = []
@@ -141,33 +123,11 @@ if __name__ == "__main__":
                 row.append(f"xcd={knob >> 4}: {us:7.1f}us {tf:4.0f}TF {gbs:5.0f}GB/s")
             print(f"{name:28s} " + " | ".join(row), flush=True)
         L.llie_tune(b"gemm_ablate", 0)
-    if "one" in sys.argv[1:]:  # one shape, for PMC passes: gpu_tune.py one <shape index> [gemm_big knob]
+    if "one" in sys.argv[1:]:  # one shape, for PMC passes: gpu_tune.py one <shape index>
         i = sys.argv.index("one")
         name, kind, P, segs, n = SHAPES[int(sys.argv[i + 1])]
-        L.llie_tune(b"gemm_big", int(sys.argv[i + 2]) if len(sys.argv) > i + 2 else 0)
         us, gbs, tf = gemm(kind, B * P, segs, n, P, act=3 if kind == "k1" else 1)
         print(f"{name}: {us:.1f} us {tf:.0f} TF {gbs:.0f} GB/s")
-    if "big" in sys.argv[1:]:
-        torch.manual_seed(0)
-        for name, kind, P, segs, n in SHAPES:
-            if n % 128:
-                continue
-            row = []
-            ref = None
-            for knob in (0, 8, 0, 8):
-                L.llie_tune(b"gemm_big", knob)
-                torch.manual_seed(1)
-                us, gbs, tf = gemm(kind, B * P, segs, n, P, act=3 if kind == "k1" else 1)
-                o, st_ = gemm.last
-                if ref is None:
-                    ref = (o.clone(), st_.clone())
-                    eq = ""
-                else:
-                    # statistics slabs differ in layout only if the tile rows differ (they do not: 128 rows per partial)
-                    eq = f" eq={int(torch.equal(o, ref[0]))}{int(torch.equal(st_, ref[1]))}"
-                row.append(f"big={knob}: {us:7.1f}us {tf:4.0f}TF {gbs:5.0f}GB/s{eq}")
-            print(f"{name:28s} " + " | ".join(row), flush=True)
-        L.llie_tune(b"gemm_big", 0)
     if "dw" in sys.argv[1:]:
         for rep in range(2):
             for H, Cc in [(256, 128), (256, 384), (128, 768), (64, 1536)]:
