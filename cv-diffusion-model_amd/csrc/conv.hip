@@ -96,23 +96,23 @@ __global__ void __launch_bounds__(256) init_conv_kernel(const InitConvArgs a) {
 template <typename T>
 __global__ void __launch_bounds__(256) init_conv_mfma_kernel(const InitConvArgs a) {
   typedef typename Elem<T>::vec_t vec_t;
-  constexpr int PWD = 19;
-  __shared__ vec_t patch[18 * PWD + 1];   // +1: an all-zero slot for the missing 10th tap
+  constexpr int TH = 8, TW = 32, PH = TH + 2, PWD = TW + 3;  // 8 x 32 output tile: 136-byte runs of the fp32 input planes
+  __shared__ vec_t patch[PH * PWD + 1];   // +1: an all-zero slot for the missing 10th tap
   __shared__ float ctile[4][32 * 33];
   __shared__ float red[4][2][32];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int tiles_x = a.W / 16;
+  const int tiles_x = a.W / TW;
   const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x, b = blockIdx.y;
-  const int x0 = tx * 16, y0 = ty * 16;
+  const int x0 = tx * TW, y0 = ty * TH;
   const int Cin = a.c0 + a.c1;
   const size_t plane = (size_t)a.H * a.W;
-  for (int i = tid; i < 18 * PWD + 1; i += 256) {
+  for (int i = tid; i < PH * PWD + 1; i += 256) {
     const int py = i / PWD, px = i % PWD;
     const int gy = y0 + py - 1, gx = x0 + px - 1;
     vec_t v;
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = (T)0.f;
-    if (i < 18 * PWD && px < 18 && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {
+    if (i < PH * PWD && px < TW + 2 && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {
       for (int ci = 0; ci < Cin; ++ci) {
         const float* src = ci < a.c0 ? a.x0 + ((size_t)b * a.c0 + ci) * plane : a.x1 + ((size_t)b * a.c1 + (ci - a.c0)) * plane;
         v[ci] = (T)src[(size_t)gy * a.W + gx];
@@ -124,7 +124,7 @@ __global__ void __launch_bounds__(256) init_conv_mfma_kernel(const InitConvArgs 
   const int r = lane & 31, h = lane >> 5;
   const T* wp = reinterpret_cast<const T*>(a.wp);
   T* out = reinterpret_cast<T*>(a.out) + (size_t)b * a.H * a.W * a.Cout;
-  const int ntiles = tiles_x * (a.H / 16);
+  const int ntiles = tiles_x * (a.H / TH);
   float* ct = ctile[wave];
   for (int oc0 = 0; oc0 < a.Cout; oc0 += 32) {
     vec_t wf[5];
@@ -134,15 +134,15 @@ __global__ void __launch_bounds__(256) init_conv_mfma_kernel(const InitConvArgs 
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-      const int g = wave * 2 + t;                 // 32-pixel group: rows 2g, 2g+1 of the 16x16 tile
-      const int py = 2 * g + (r >> 4), px = r & 15;
+      const int g = wave * 2 + t;                 // 32-pixel group: row g of the 8 x 32 tile
+      const int py = g, px = r;
       f32x16 acc;
 #pragma unroll
       for (int q = 0; q < 16; ++q) acc[q] = 0.f;
 #pragma unroll
       for (int s = 0; s < 5; ++s) {
         const int tap = 2 * s + h;
-        const int idx = tap < 9 ? (py + tap / 3) * PWD + px + tap % 3 : 18 * PWD;
+        const int idx = tap < 9 ? (py + tap / 3) * PWD + px + tap % 3 : PH * PWD;
         const vec_t av = patch[idx];
         if constexpr (std::is_same<T, half_t>::value) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, wf[s], acc, 0, 0, 0);
         else acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, wf[s], acc, 0, 0, 0);
@@ -163,7 +163,7 @@ __global__ void __launch_bounds__(256) init_conv_mfma_kernel(const InitConvArgs 
         float f[16];
 #pragma unroll
         for (int e = 0; e < 16; ++e) f[e] = ct[p * 33 + half * 16 + e];
-        const int oy = y0 + 2 * g + (p >> 4), ox = x0 + (p & 15);
+        const int oy = y0 + g, ox = x0 + p;
         T* dst = out + ((size_t)oy * a.W + ox) * a.Cout + oc0 + half * 16;
         st_vec<T>(dst, f32_to_vec<T>(f));
         st_vec<T>(dst + 8, f32_to_vec<T>(f + 8));
@@ -190,7 +190,8 @@ __global__ void __launch_bounds__(256) init_conv_mfma_kernel(const InitConvArgs 
 int init_conv_ntiles(int H, int W) { return (H / 16) * (W / 16); }
 hipError_t launch_init_conv(int dtype, const InitConvArgs& a, hipStream_t s) {
   if (a.H % 16 || a.W % 16 || a.Cout % 32 || a.c0 + a.c1 > 8) return hipErrorInvalidValue;
-  dim3 grid((a.H / 16) * (a.W / 16), a.B);
+  if (a.wp && dtype != 0 && a.W % 32) return hipErrorInvalidValue;
+  dim3 grid((a.H / 16) * (a.W / 16), a.B);  // 256-pixel tiles: 16 x 16 (VALU kernel) or 8 x 32 (MFMA kernel)
   switch (dtype) {
     case 0: hipLaunchKernelGGL(init_conv_kernel<float>, grid, dim3(256), 0, s, a); break;
     case 1:
@@ -268,15 +269,17 @@ __global__ void __launch_bounds__(256) final_conv_kernel(const FinalConvArgs a) 
 // low_light_diffusion.py:240) is per-lane and its fp32 NCHW accesses are 64-byte row segments.
 // K order per 32-channel chunk: k-step = (tap, 16-channel half); lane half h takes 8 channels.
 // Weights pre-packed as [chunk][18][2][4][8] T (output channel padded to 4).
-template <typename T>
+template <typename T, int TW>
 __global__ void __launch_bounds__(256) final_conv_mfma_kernel(const FinalConvArgs a) {
   typedef typename Elem<T>::vec_t vec_t;
-  constexpr int PWD = 19, PIX = 40;  // pixel pitch 80 B: conflict-free ds_read_b128 (cf. TilePitch)
-  __shared__ __align__(16) T patch[(18 * PWD + 1) * PIX];
+  // output tile (256 / TW) x TW pixels.  TW = 16 is used: 8 x 32 tiles (128-byte instead of 64-byte runs on the fp32 planes
+  // of the scheduler step) measured 210 us against 163 us at B = 32 -- this kernel is not bound by its coalescing
+  constexpr int TH = 256 / TW, PH = TH + 2, PWD = TW + 3, PIX = 40;  // pixel pitch 80 B: conflict-free ds_read_b128 (cf. TilePitch)
+  __shared__ __align__(16) T patch[(PH * PWD + 1) * PIX];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int tiles_x = a.W / 16;
+  const int tiles_x = a.W / TW;
   const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x, b = blockIdx.y;
-  const int x0 = tx * 16, y0 = ty * 16;
+  const int x0 = tx * TW, y0 = ty * TH;
   const T* in = reinterpret_cast<const T*>(a.in) + (size_t)b * a.H * a.W * a.C;
   const T* wp = reinterpret_cast<const T*>(a.wp);
   const int r = lane & 31, h = lane >> 5;
@@ -291,7 +294,7 @@ __global__ void __launch_bounds__(256) final_conv_mfma_kernel(const FinalConvArg
 
   for (int cc = 0; cc < a.C; cc += 32) {
     if (cc) wg_barrier();
-    // stage the activated 18x18x32 patch (GroupNorm affine + SiLU applied once per element); a thread's
+    // stage the activated 10x34x32 patch (GroupNorm affine + SiLU applied once per element); a thread's
     // 8-channel slice is loop invariant (256 % 4 == 0), so its affine pairs live in registers
     const int cv = (tid & 3) * 8;
     float sc[8], sh[8];
@@ -300,12 +303,12 @@ __global__ void __launch_bounds__(256) final_conv_mfma_kernel(const FinalConvArg
       sc[e] = a.as[(size_t)b * a.C + cc + cv + e];
       sh[e] = a.ab[(size_t)b * a.C + cc + cv + e];
     }
-    for (int i = tid; i < (18 * PWD + 1) * 4; i += 256) {
+    for (int i = tid; i < (PH * PWD + 1) * 4; i += 256) {
       const int pix = i >> 2;
       const int ppy = pix / PWD, ppx = pix % PWD;
       const int gy = y0 + ppy - 1, gx = x0 + ppx - 1;
       vec_t v = zero;
-      if (pix < 18 * PWD && ppx < 18 && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {
+      if (pix < PH * PWD && ppx < TW + 2 && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {
         float f[8];
         ld_f32<T>(in + ((size_t)gy * a.W + gx) * a.C + cc + cv, f);
 #pragma unroll
@@ -323,7 +326,7 @@ __global__ void __launch_bounds__(256) final_conv_mfma_kernel(const FinalConvArg
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       const int g = wave * 2 + t;
-      const int py = 2 * g + (r >> 4), px = r & 15;
+      const int py = g * (32 / TW) + r / TW, px = r % TW;
 #pragma unroll
       for (int ks = 0; ks < 18; ++ks) {
         const int tap = ks >> 1, q = ks & 1;
@@ -340,7 +343,7 @@ __global__ void __launch_bounds__(256) final_conv_mfma_kernel(const FinalConvArg
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
     const int g = wave * 2 + t;
-    const int y = y0 + 2 * g + (r >> 4), x = x0 + (r & 15);
+    const int y = y0 + g * (32 / TW) + r / TW, x = x0 + r % TW;
 #pragma unroll
     for (int o = 0; o < 4; ++o) {
       if (o >= a.Cout) break;
@@ -370,11 +373,11 @@ hipError_t launch_final_conv(int dtype, const FinalConvArgs& a, hipStream_t s) {
   switch (dtype) {
     case 0: hipLaunchKernelGGL(final_conv_kernel<float>, grid, dim3(256), 0, s, a); break;
     case 1:
-      if (a.wp) hipLaunchKernelGGL(final_conv_mfma_kernel<half_t>, grid, dim3(256), 0, s, a);
+      if (a.wp) hipLaunchKernelGGL((final_conv_mfma_kernel<half_t, 16>), grid, dim3(256), 0, s, a);
       else hipLaunchKernelGGL(final_conv_kernel<half_t>, grid, dim3(256), 0, s, a);
       break;
     case 2:
-      if (a.wp) hipLaunchKernelGGL(final_conv_mfma_kernel<bf16_t>, grid, dim3(256), 0, s, a);
+      if (a.wp) hipLaunchKernelGGL((final_conv_mfma_kernel<bf16_t, 16>), grid, dim3(256), 0, s, a);
       else hipLaunchKernelGGL(final_conv_kernel<bf16_t>, grid, dim3(256), 0, s, a);
       break;
     default: return hipErrorInvalidValue;
