@@ -173,6 +173,7 @@ struct Tape {
 
 }  // namespace
 
+constexpr int kMaxBranches = 8;
 struct llie_ctx {
   llie_config cfg{};
   int dt = 0;
@@ -210,6 +211,9 @@ struct llie_ctx {
   // backward pass: weight-gradient kernels run on this stream next to the activation-gradient chain (Back::fork/join)
   hipStream_t side_stream = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  // concurrent branches of the captured enhance graph (branch 0 is cap_stream)
+  hipStream_t branch_stream[kMaxBranches] = {};
+  hipEvent_t branch_join[kMaxBranches] = {};
   // per-kernel-class HIP-event profiling (llie_profile_begin / llie_profile_end)
   int prof_mask = 0;
   struct ProfRec { int cls; int64_t bytes; hipEvent_t e0, e1; const char* name; char tag[56]; };
@@ -536,7 +540,7 @@ int g_bwd_async = 1;
 // half (norm finalisation, SE MLP) overlaps the streaming kernels of the other, +4 % at B = 32.  Overlapping kernels
 // stretch each other, so per-kernel durations are only meaningful from a single chain: llie_profile_* already forces
 // the eager single chain, and LLIE_ENHANCE_SPLIT=0 (or llie_tune("enhance_split", 0)) gives rocprofv3 the same.
-int g_enhance_split = getenv("LLIE_ENHANCE_SPLIT") ? atoi(getenv("LLIE_ENHANCE_SPLIT")) : 1;
+int g_enhance_split = getenv("LLIE_ENHANCE_SPLIT") ? atoi(getenv("LLIE_ENHANCE_SPLIT")) : 2;
 // Captured graphs bake in the kernel choices of the moment: every llie_tune call starts a new epoch of the graph cache.
 int g_tune_epoch = 0;
 int tune_epoch() { return g_tune_epoch; }
@@ -1583,6 +1587,10 @@ void llie_destroy(llie_ctx* c) {
   }
   if (c->cap_stream) (void)hipStreamDestroy(c->cap_stream);
   if (c->side_stream) (void)hipStreamDestroy(c->side_stream);
+  for (int i = 0; i < kMaxBranches; ++i) {
+    if (c->branch_stream[i]) (void)hipStreamDestroy(c->branch_stream[i]);
+    if (c->branch_join[i]) (void)hipEventDestroy(c->branch_join[i]);
+  }
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
   if (c->ev_join) (void)hipEventDestroy(c->ev_join);
   for (auto& r : c->prof) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
@@ -2017,31 +2025,48 @@ int llie_enhance(llie_ctx* c, const float* low, const float* noise, const int64_
     e = hipStreamBeginCapture(c->cap_stream, hipStreamCaptureModeThreadLocal);
     if (e != hipSuccess) { set_err("hipStreamBeginCapture: %s", hipGetErrorString(e)); return (int)e; }
     int rc = LLIE_OK;
-    // Two half-batches as two concurrent branches of the graph: no operator mixes samples and every kernel is
-    // bitwise batch-invariant, so the result is unchanged; memory-bound kernels of one branch overlap with the
-    // latency / MFMA-bound ones of the other (llie_tune("enhance_split", 0) captures a single chain).
-    const int hA = batch / 2, hB = batch - hA;
-    const int64_t wsA = hA > 0 ? llie_workspace_bytes(c, hA, 0, 0) : 0, wsB = llie_workspace_bytes(c, hB, 0, 0);
-    const bool split = g_enhance_split && hA >= 8 && wsA > 0 && wsB > 0 && (int64_t)align_up((size_t)wsA, 256) + wsB <= seq_bytes;
-    if (split) {
+    // The batch as g_enhance_split (default 2) concurrent branches of the graph: no operator mixes samples and every kernel
+    // is bitwise batch-invariant, so the result is unchanged; memory-bound kernels of one branch overlap with the
+    // latency / MFMA-bound ones and the launch boundaries of the others (llie_tune("enhance_split", 0 or 1): a single chain).
+    int nbr = g_enhance_split < 2 ? 1 : (g_enhance_split > kMaxBranches ? kMaxBranches : g_enhance_split);
+    while (nbr > 1 && batch / nbr < 8) --nbr;  // branches of fewer than 8 images lose more in kernel efficiency than they hide
+    int hb[kMaxBranches];
+    size_t woff[kMaxBranches];
+    int64_t wsz[kMaxBranches];
+    size_t wtot = 0;
+    for (int i = 0; i < nbr; ++i) {
+      hb[i] = batch / nbr + (i < batch % nbr ? 1 : 0);
+      wsz[i] = llie_workspace_bytes(c, hb[i], 0, 0);
+      if (wsz[i] <= 0) { nbr = 1; break; }
+      woff[i] = wtot;
+      wtot += align_up((size_t)wsz[i], 256);
+    }
+    if (nbr > 1 && (int64_t)wtot > seq_bytes) nbr = 1;
+    if (nbr > 1) {
       hipError_t e2 = hipSuccess;
-      if (!c->side_stream) e2 = hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking);
-      if (e2 == hipSuccess && !c->ev_fork) e2 = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
-      if (e2 == hipSuccess && !c->ev_join) e2 = hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming);
+      if (!c->ev_fork) e2 = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
+      for (int i = 1; i < nbr && e2 == hipSuccess; ++i) {
+        if (!c->branch_stream[i]) e2 = hipStreamCreateWithFlags(&c->branch_stream[i], hipStreamNonBlocking);
+        if (e2 == hipSuccess && !c->branch_join[i]) e2 = hipEventCreateWithFlags(&c->branch_join[i], hipEventDisableTiming);
+      }
       if (e2 == hipSuccess) e2 = hipEventRecord(c->ev_fork, c->cap_stream);
-      if (e2 == hipSuccess) e2 = hipStreamWaitEvent(c->side_stream, c->ev_fork, 0);  // the side stream joins the capture
+      for (int i = 1; i < nbr && e2 == hipSuccess; ++i) e2 = hipStreamWaitEvent(c->branch_stream[i], c->ev_fork, 0);  // joins the capture
       if (e2 != hipSuccess) { hipGraph_t gd = nullptr; (void)hipStreamEndCapture(c->cap_stream, &gd); if (gd) (void)hipGraphDestroy(gd);
                               set_err("enhance split: %s", hipGetErrorString(e2)); return (int)e2; }
-      const size_t offA = (size_t)hA * 3 * S * S;
-      rc = enhance_sequence(c, s_low, s_noise, s_t, coefs, steps, s_enh, s_inter, s_preds, hA, base, wsA,
-                            reinterpret_cast<llie_stream>(c->cap_stream), batch);
-      const int rc2 = enhance_sequence(c, s_low + offA, s_noise + offA, s_t + hA, coefs, steps, s_enh + offA,
-                                       s_inter ? s_inter + offA : nullptr, s_preds ? s_preds + offA : nullptr, hB,
-                                       base + align_up((size_t)wsA, 256), wsB, reinterpret_cast<llie_stream>(c->side_stream), batch);
-      if (rc == LLIE_OK) rc = rc2;
-      e2 = hipEventRecord(c->ev_join, c->side_stream);
-      if (e2 == hipSuccess) e2 = hipStreamWaitEvent(c->cap_stream, c->ev_join, 0);
-      if (e2 != hipSuccess && rc == LLIE_OK) { set_err("enhance split join: %s", hipGetErrorString(e2)); rc = (int)e2; }
+      size_t img0 = 0;  // first image of the branch
+      for (int i = 0; i < nbr; ++i) {
+        const size_t off = img0 * 3 * S * S;
+        hipStream_t bs = i == 0 ? c->cap_stream : c->branch_stream[i];
+        const int rci = enhance_sequence(c, s_low + off, s_noise + off, s_t + img0, coefs, steps, s_enh + off, s_inter ? s_inter + off : nullptr,
+                                         s_preds ? s_preds + off : nullptr, hb[i], base + woff[i], wsz[i], reinterpret_cast<llie_stream>(bs), batch);
+        if (rc == LLIE_OK) rc = rci;
+        img0 += hb[i];
+      }
+      for (int i = 1; i < nbr; ++i) {
+        e2 = hipEventRecord(c->branch_join[i], c->branch_stream[i]);
+        if (e2 == hipSuccess) e2 = hipStreamWaitEvent(c->cap_stream, c->branch_join[i], 0);
+        if (e2 != hipSuccess && rc == LLIE_OK) { set_err("enhance split join: %s", hipGetErrorString(e2)); rc = (int)e2; }
+      }
     } else {
       rc = enhance_sequence(c, s_low, s_noise, s_t, coefs, steps, s_enh, s_inter, s_preds, batch, base, seq_bytes,
                             reinterpret_cast<llie_stream>(c->cap_stream));

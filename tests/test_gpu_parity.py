@@ -454,18 +454,20 @@ def test_unpinned_variants_vs_oracle(dev, variant, size, batch):
 
 
 def test_split_batch_graph_capture_is_bitwise_identical(dev):
-    """Opt-in `enhance_split`: the hipGraph of `enhance` is captured as two concurrent half-batch branches; every kernel
-    is batch-invariant, so the output bits do not change (B=16: halves of 8)."""
+    """`enhance_split` = number of concurrent batch branches the hipGraph of `enhance` is captured as (default 2 from 16
+    images on; 1 = a single chain): every kernel is batch-invariant, so the output bits do not change (B=32: one chain,
+    halves of 16, quarters of 8)."""
     native = importlib.import_module("cv-diffusion-model_amd._native")
     m, sd, spec = small_model(64, dev)
     m.compute_dtype = "fp16"
-    low = (torch.rand(16, 3, 64, 64, generator=torch.Generator().manual_seed(8)) * 2 - 1).to(dev)
-    noise = torch.randn(4, 16, 3, 64, 64, generator=torch.Generator().manual_seed(9)).to(dev)
+    low = (torch.rand(32, 3, 64, 64, generator=torch.Generator().manual_seed(8)) * 2 - 1).to(dev)
+    noise = torch.randn(4, 32, 3, 64, 64, generator=torch.Generator().manual_seed(9)).to(dev)
     try:
-        ref = [m.enhance(low, 4, noise=noise) for _ in range(3)][-1]      # eager, then captured as one chain
-        native.lib().llie_tune(b"enhance_split", 1)
-        out = [m.enhance(low, 4, noise=noise) for _ in range(3)][-1]      # eager, then captured as two branches
-        assert torch.equal(out, ref)
+        outs = []
+        for branches in (1, 2, 4):
+            native.lib().llie_tune(b"enhance_split", branches)
+            outs.append([m.enhance(low, 4, noise=noise) for _ in range(3)][-1])   # eager, then captured, then replayed
+        assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
     finally:
-        native.lib().llie_tune(b"enhance_split", 0)
+        native.lib().llie_tune(b"enhance_split", 2)
         m.compute_dtype = None

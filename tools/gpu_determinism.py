@@ -21,7 +21,7 @@ noise = torch.randn(4, B, 3, 256, 256, generator=g).to(dev)
 res = {}
 if len(sys.argv) > 2:  # bisect: split on, recompute kernels restricted to some input widths / variants
     for mask, dbuf in [(1, 1), (1, 0), (2, 0), (4, 0), (3, 1), (7, 1)]:
-        N.check(L.llie_tune(b"irbx", 1)); N.check(L.llie_tune(b"enhance_split", 1))
+        N.check(L.llie_tune(b"irbx", 1)); N.check(L.llie_tune(b"enhance_split", 2))
         N.check(L.llie_tune(b"irbx_mask", mask)); N.check(L.llie_tune(b"irbx_dbuf", dbuf))
         outs = [m.enhance(low, 4, noise=noise, return_intermediate=True).intermediate[-1].clone() for _ in range(5)]
         eq = [torch.equal(outs[0], o) for o in outs[1:]]
@@ -32,7 +32,7 @@ if len(sys.argv) > 2:  # bisect: split on, recompute kernels restricted to some 
 for irbx in (0, 1):
     for split in (0, 1):
         N.check(L.llie_tune(b"irbx", irbx))
-        N.check(L.llie_tune(b"enhance_split", split))
+        N.check(L.llie_tune(b"enhance_split", 1 + split))
         outs = [m.enhance(low, 4, noise=noise, return_intermediate=True).intermediate[-1].clone() for _ in range(4)]
         res[(irbx, split)] = outs
         print(f"irbx={irbx} split={split}: call1(eager)==call2(graph) {torch.equal(outs[0], outs[1])}  call2==call3 {torch.equal(outs[1], outs[2])} "
