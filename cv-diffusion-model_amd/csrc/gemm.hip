@@ -386,8 +386,9 @@ static hipError_t launch_cfg(const GemmArgs& a, hipStream_t s) {
 int pw_gemm_tile_rows(int P) { return (P % 128 == 0) ? 128 : 64; }
 
 // tuning knobs for tools/gpu_tune.py (0 = automatic)
-static int g_force_bk = 0;
+static int g_force_bk = 0, g_bk128 = 1024;
 void pw_gemm_force_bk(int bk) { g_force_bk = bk; }
+void pw_gemm_bk128(int v) { g_bk128 = v; }
 
 template <typename T>
 static hipError_t launch_t(const GemmArgs& a, hipStream_t s) {
@@ -396,6 +397,16 @@ static hipError_t launch_t(const GemmArgs& a, hipStream_t s) {
   bool k64 = sizeof(T) == 2;  // BK = 64 needs every K segment to be a multiple of 64 (2-byte T only)
   for (int i = 0; i < a.nseg; ++i) k64 = k64 && (a.seg[i].ch % 64 == 0);
   if (g_force_bk == 32) k64 = false;
+  if constexpr (sizeof(T) == 2) {
+    // small grids (about as many workgroups as the chip holds at once): a workgroup's time is chunks x memory latency, so
+    // twice the chunk: -10...-16 % on the long-K project layers of the low resolutions (and at B = 1), +10 % on large grids.
+    // The sequence of 32-wide k-steps per accumulator is unchanged: same bits, whatever the batch size chooses
+    if (g_bk128 && BM == 128 && BN == 128 && (long)(a.M / 128) * (a.N / 128) <= g_bk128) {
+      bool k128 = true;
+      for (int i = 0; i < a.nseg; ++i) k128 = k128 && (a.seg[i].ch % 128 == 0);
+      if (k128) return launch_cfg<T, 128, 128, 2, 2, 128>(a, s);
+    }
+  }
   if (BM == 128) {
     if (BN == 128) return k64 ? launch_cfg<T, 128, 128, 2, 2, 64>(a, s) : launch_cfg<T, 128, 128, 2, 2, 32>(a, s);
     if (BN == 64) return k64 ? launch_cfg<T, 128, 64, 2, 2, 64>(a, s) : launch_cfg<T, 128, 64, 2, 2, 32>(a, s);

@@ -114,6 +114,19 @@ if __name__ == "__main__":
             print(f"{name:28s} {us0:8.1f} us ({us:8.1f} stamped)  per wave: K loop {out[0]:9.0f} cyc ({100*out[0]/max(tot,1):4.1f}%)  epilogue {out[1]:9.0f} cyc "
                   f"({100*out[1]/max(tot,1):4.1f}%)  waves {out[2]:.0f}", flush=True)
         L.llie_tune(b"gemm_stamp", 0)
+    if "bk128" in sys.argv[1:]:  # 128-wide K chunks; usage: gpu_tune.py bk128 [B]
+        i = sys.argv.index("bk128")
+        Bx = int(sys.argv[i + 1]) if len(sys.argv) > i + 1 else 32
+        for name, kind, P, segs, n in SHAPES + [("attn qkv 256->768", "k1", 1024, [256], 768), ("attn out 256->256", "k3", 1024, [256], 256), ("enc3.0 K3 512->256", "k3", 1024, [512], 256)]:
+            if n % 128 or any(c % 128 for c in segs):
+                continue
+            row = []
+            for knob in (0, 1 << 30, 0, 1 << 30):
+                L.llie_tune(b"gemm_bk128", knob)
+                us, gbs, tf = gemm(kind, Bx * P, segs, n, P, act=3 if kind == "k1" else 1, B=Bx)
+                row.append(f"bk={128 if knob else 64}: {us:6.1f}us")
+            print(f"B={Bx} grid={(Bx * P // 128) * (n // 128):6d} {name:28s} " + " | ".join(row), flush=True)
+        L.llie_tune(b"gemm_bk128", 0)
     if "xcd" in sys.argv[1:]:  # XCD-aware tile order of the production kernel (gemm_ablate bit 4)
         for name, kind, P, segs, n in SHAPES:
             row = []
