@@ -63,6 +63,7 @@ class LCMScheduler:
         self._step_index = None
         self._timestep_list: List[int] = []
         self._acp_dev = {}
+        self._ts_dev = {}
 
     @staticmethod
     def _cosine_betas(n: int, s: float = 0.008) -> torch.Tensor:  # :107-114
@@ -82,9 +83,20 @@ class LCMScheduler:
         skipping_step = len(origin) // num_inference_steps
         ts = origin[::skipping_step][:num_inference_steps].flip(0)  # slice step 0 -> ValueError, like the reference
         self._timestep_list = [int(v) for v in ts.tolist()]
-        self.timesteps = ts.to(device)
+        # device copies are cached per (schedule, device): a pageable host-to-device copy blocks the host until the stream
+        # has drained, i.e. every `enhance` call would wait for the previous one and leave the GPU idle while Python
+        # prepares the next launch (measured: 0.7 ms of exposed host time per call, 10 % of a B=1 call)
+        dev = torch.device(device)
+        key = (tuple(self._timestep_list), dev.type, dev.index)
+        cached = self._ts_dev.get(key)
+        if cached is None:
+            if len(self._ts_dev) > 64:
+                self._ts_dev.clear()
+            cached = self._ts_dev[key] = ts.to(dev)
+        self.timesteps = cached
         self._step_index = 0
-        self.sigmas = self.sigmas.to(device)
+        if self.sigmas.device != dev:
+            self.sigmas = self.sigmas.to(dev)
 
     def _get_prev_timestep(self, timestep: int) -> int:  # :169-174, without the device round trip
         idx = self._timestep_list.index(int(timestep))
