@@ -552,7 +552,7 @@ int irbx_stats_rows(int P) {
   return rp;
 }
 
-static int g_irbx_dbuf = 1, g_irbx_tiles = 4, g_irbx_stamp = 0, g_irbx_ablate = 0;
+static int g_irbx_dbuf = 0, g_irbx_tiles = 4, g_irbx_stamp = 0, g_irbx_ablate = 0;
 void irbx_ablate(int v) { g_irbx_ablate = v; }
 static unsigned long long* g_irbx_dbg = nullptr;
 static size_t g_irbx_dbg_n = 0;  // entries of the last stamped launch
@@ -652,7 +652,8 @@ static hipError_t launch_dw_cfg(const IrbxArgs& a, hipStream_t s) {
 template <typename T>
 static hipError_t launch_dw_t(const IrbxArgs& a, hipStream_t s) {
   const int Cin = a.c0 + a.c1;
-  // double-buffered h1 tile (one barrier per chunk) while two workgroups still fit a CU's 160 KB of LDS
+  // llie_tune("irbx_dbuf", 1): double-buffered h1 tile for the 32-channel inputs (one barrier per chunk, 76 KB of LDS = two
+  // workgroups per CU).  The single-buffered kernel (49 KB, three workgroups per CU) is the default: 1 % faster end to end
   if (g_irbx_dbuf) {
     switch (Cin) {
       case 32: return launch_dw_cfg<T, 2, true>(a, s);

@@ -345,7 +345,7 @@ def test_recompute_form_is_race_free_under_concurrency(dev):
                 for o, s0 in zip(outs, solo):
                     assert torch.equal(o, s0), f"dbuf={dbuf}"
     finally:
-        N.check(L.llie_tune(b"irbx_dbuf", 1))
+        N.check(L.llie_tune(b"irbx_dbuf", 0))
 
 
 def test_copy_probe_copies(dev):
