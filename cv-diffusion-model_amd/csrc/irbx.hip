@@ -113,7 +113,7 @@ __global__ void __launch_bounds__(256, 2) expand_stats_kernel(const IrbxArgs a, 
     }
     if (step + 1 < nsteps) load(step + 1);
     wg_barrier();  // tile `step` complete; the other buffer (read during step - 1) is free for step + 1
-#pragma unroll
+#pragma unroll 1
     for (int pb = 0; pb < 4; ++pb) {
       vec_t af[KS];
 #pragma unroll
@@ -125,14 +125,17 @@ __global__ void __launch_bounds__(256, 2) expand_stats_kernel(const IrbxArgs a, 
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
         for (int s = 0; s < KS; ++s) acc = mfma16<T>(af[s], wf[j][s], acc);
-        float t1 = 0.f, t2 = 0.f;
+        // packed fp32 (v_pk_add_f32 / v_pk_fma_f32: two values per instruction) -- this reduction, not the MFMAs, is what
+        // the wave spends its issue slots on
+        f32x2 t1 = {0.f, 0.f}, t2 = {0.f, 0.f};
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          t1 += acc[r];
-          t2 += acc[r] * acc[r];
+        for (int r = 0; r < 16; r += 2) {
+          const f32x2 v = {acc[r], acc[r + 1]};
+          t1 += v;
+          t2 = __builtin_elementwise_fma(v, v, t2);
         }
-        s1[j] += t1;
-        s2[j] += t2;
+        s1[j] += t1[0] + t1[1];
+        s2[j] += t2[0] + t2[1];
       }
     }
   }

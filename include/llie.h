@@ -219,7 +219,16 @@ int llie_dwconv3x3_tiles(int H, int W);
 /* dst[0:bytes] = src[0:bytes] with 16-byte lane accesses: the on-box HBM copy-bandwidth probe behind bench.py's
  * `peak_measured` ("a copy-kernel bandwidth probe"; 2 x bytes move per call). */
 int llie_copy_probe(const void* src, void* dst, int64_t bytes, llie_stream stream);
-int llie_tune(const char* knob, int value); /* tuning knobs for tools/gpu_tune.py: "gemm_bk" = 0 (auto) | 32 */
+/* Engine knobs (process-wide; every call starts a new epoch of the hipGraph cache).  Production defaults in brackets.
+ *   "enhance_split"  [2]    concurrent batch branches of the captured enhance graph (1 = one chain; env LLIE_ENHANCE_SPLIT)
+ *   "irbx"           [1]    recompute form of the inverted-residual front half (0 = expand GEMM + depthwise kernel)
+ *   "irbx_dbuf" [0], "irbx_tiles" [4], "irbx_mask" [7]   variants of the recompute kernels (A/B runs)
+ *   "ztot"           [1]    SE pool as fixed-point totals + fused gate kernel (0 = slab + pool / fc1 / fc2 launches)
+ *   "gemm_bk" [0 = auto], "gemm_bk128" [1024 = largest grid that takes 128-wide K chunks], "dw_swap" [0],
+ *   "bwd_async" [1], "wgrad_target" [1024]
+ * Diagnostics whose results are WRONG or slow (timing studies only): "skip_small", "gemm_ablate", "dw_ablate",
+ * "irbx_ablate", "gemm_stamp", "irbx_stamp". */
+int llie_tune(const char* knob, int value);
 int llie_debug_irbx_stamps(double* out4); /* diagnostic builds: see irbx.hip (STAMP) */
 int llie_debug_gemm_stamps(double* out3); /* diagnostic builds: see gemm.hip (STAMP) */
 
