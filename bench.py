@@ -383,6 +383,18 @@ def kernel_class_of(name: str, native) -> int:
     return native.K_OTHER
 
 
+def pmc_lookup(kernels: dict, name: str):
+    """HBM bytes per launch of kernel `name` in a tools/pmc_summary.py table.  Its demangler prints template arguments it
+    cannot resolve (bool / defaulted ones) as `?`: `pw_gemm_kernel<_Float16, 128, 128, 2, 2, 64, ?, ?, ?>` is the launcher's
+    `pw_gemm_kernel<_Float16, 128, 128, 2, 2, 64>`; the longest prefix match on the resolved arguments wins."""
+    best, best_len = None, -1
+    for key, v in kernels.items():
+        stem = key.replace(", ?", "").rstrip(">")
+        if (name == stem + ">" or name.startswith(stem + ",")) and len(stem) > best_len:
+            best, best_len = v, len(stem)
+    return best["hbm_bytes_per_launch"] if best else None
+
+
 def roofline(handle, native, args, breakdown, dom_prof, step_seconds: float, peak_measured: float) -> dict:
     """Roofline of the dominant kernel from HIP events recorded on the launch stream (engine hooks llie_profile_begin /
     llie_profile_report, aggregated per kernel name -- the granularity of `rocprofv3 --kernel-trace --stats`), collected
@@ -401,9 +413,7 @@ def roofline(handle, native, args, breakdown, dom_prof, step_seconds: float, pea
     pmc = os.path.join(ROOT, "profiles", "r02", "pmc_traffic.json")
     default_cfg = (args.variant, args.image_size, args.batch, args.lcm_steps, args.dtype) == ("small", 256, 32, 4, "fp16")
     if default_cfg and os.path.exists(pmc):
-        k = json.load(open(pmc)).get("kernels", {}).get(dom)
-        if k:
-            traffic = k["hbm_bytes_per_launch"]
+        traffic = pmc_lookup(json.load(open(pmc)).get("kernels", {}), dom)
     fwd = handle.algorithmic_bytes(args.batch)
     path = handle.path_bytes(args.batch)
     whole = args.lcm_steps * fwd / step_seconds / 1e9

@@ -361,3 +361,13 @@ def test_bench_kernel_class_mapping():
     assert b.kernel_class_of("conv3x3_kernel<_Float16, 1, 16, 128, 2, 2>", native) == native.K_CONV3
     assert b.kernel_class_of("se_pool_kernel+se_fc1_kernel+se_fc2_kernel", native) == native.K_SE
     assert b.kernel_class_of("gn_finalize_kernel", native) == native.K_OTHER
+    assert b.kernel_class_of("se_gate_kernel", native) == native.K_SE
+    assert b.kernel_class_of("se_fc1_kernel+se_fc2_kernel", native) == native.K_SE
+    # PMC table keys carry `?` for template arguments the demangler cannot resolve: longest resolved-prefix match
+    table = {"pw_gemm_kernel<_Float16, 128, 128, 2, 2, 64, ?, ?, ?>": {"hbm_bytes_per_launch": 1},
+             "pw_gemm_kernel<_Float16, 128, 128, 2, 2, 128, ?, ?, ?>": {"hbm_bytes_per_launch": 2},
+             "expand_dw_kernel<_Float16, 2, ?, ?, ?>": {"hbm_bytes_per_launch": 3}}
+    assert b.pmc_lookup(table, "pw_gemm_kernel<_Float16, 128, 128, 2, 2, 64>") == 1
+    assert b.pmc_lookup(table, "pw_gemm_kernel<_Float16, 128, 128, 2, 2, 128>") == 2
+    assert b.pmc_lookup(table, "expand_dw_kernel<_Float16, 2, 0>") == 3
+    assert b.pmc_lookup(table, "expand_dw_kernel<_Float16, 4, 0>") is None
