@@ -167,7 +167,7 @@ constexpr int SHP = 144;
 
 // STAMP = diagnostic build (llie_tune("irbx_stamp", 1)): s_memtime around the phases, summed per wave into a.dbg
 // ([workgroup][wave][4] = {tile prologue, MFMA phase, barrier wait, depthwise phase} cycles); never used in production.
-// ABL (diagnostic builds only): timing ablations -- 1 no h2 stores, 2 no pool sums, 8 no depthwise MFMAs.
+// ABL (diagnostic builds only): timing ablations -- 1 no h2 stores, 2 no pool sums, 4 h2 stores confined to L2, 8 no depthwise MFMAs.
 template <typename T, int KS, bool DBUF, bool STAMP = false, int ABL = 0>
 __global__ void __launch_bounds__(256, 2) expand_dw_kernel(const IrbxArgs a, const int tiles_per_wg, const int chunks_per_wg) {
   constexpr int K = 16 * KS;
@@ -467,6 +467,8 @@ __global__ void __launch_bounds__(256, 2) expand_dw_kernel(const IrbxArgs a, con
             hi2[j] = r13[0]; hi2[2 + j] = r13[1];
           }
           T* op = out + ((size_t)(y0 + drow[blk]) * a.W + x0p + (n & 15)) * a.Chid + chunk * 64 + chb * 32 + 16 * h;
+          if constexpr ((ABL & 4) != 0)  // timing ablation: every tile row lands in image row 0..7 -> the stores hit in L2, no HBM writes
+            op = out + ((size_t)(drow[blk]) * a.W + x0p + (n & 15)) * a.Chid + chunk * 64 + chb * 32 + 16 * h;
           if constexpr (!(ABL & 1)) {
             *reinterpret_cast<u32x4*>(op) = lo;
             *reinterpret_cast<u32x4*>(op + 8) = hi2;
@@ -643,6 +645,7 @@ static hipError_t launch_dw_cfg(const IrbxArgs& a, hipStream_t s) {
         case 1: return go(&expand_dw_kernel<T, KS, DBUF, true, 1>);
         case 2: return go(&expand_dw_kernel<T, KS, DBUF, true, 2>);
         case 3: return go(&expand_dw_kernel<T, KS, DBUF, true, 3>);
+        case 4: return go(&expand_dw_kernel<T, KS, DBUF, true, 4>);
         case 8: return go(&expand_dw_kernel<T, KS, DBUF, true, 8>);
         case 11: return go(&expand_dw_kernel<T, KS, DBUF, true, 11>);
       }
