@@ -167,7 +167,8 @@ constexpr int SHP = 144;
 
 // STAMP = diagnostic build (llie_tune("irbx_stamp", 1)): s_memtime around the phases, summed per wave into a.dbg
 // ([workgroup][wave][4] = {tile prologue, MFMA phase, barrier wait, depthwise phase} cycles); never used in production.
-// ABL (diagnostic builds only): timing ablations -- 1 no h2 stores, 2 no pool sums, 4 h2 stores confined to L2, 8 no depthwise MFMAs.
+// ABL (diagnostic builds only): timing ablations -- 1 no h2 stores, 2 no pool sums, 4 h2 stores confined to L2, 8 no depthwise MFMAs,
+// 16 h2 stores as contiguous kilobytes (wrong layout, same bytes).
 template <typename T, int KS, bool DBUF, bool STAMP = false, int ABL = 0>
 __global__ void __launch_bounds__(256, 2) expand_dw_kernel(const IrbxArgs a, const int tiles_per_wg, const int chunks_per_wg) {
   constexpr int K = 16 * KS;
@@ -469,7 +470,11 @@ __global__ void __launch_bounds__(256, 2) expand_dw_kernel(const IrbxArgs a, con
           T* op = out + ((size_t)(y0 + drow[blk]) * a.W + x0p + (n & 15)) * a.Chid + chunk * 64 + chb * 32 + 16 * h;
           if constexpr ((ABL & 4) != 0)  // timing ablation: every tile row lands in image row 0..7 -> the stores hit in L2, no HBM writes
             op = out + ((size_t)(drow[blk]) * a.W + x0p + (n & 15)) * a.Chid + chunk * 64 + chb * 32 + 16 * h;
-          if constexpr (!(ABL & 1)) {
+          if constexpr ((ABL & 16) != 0) {  // timing ablation (wrong layout, same bytes): both stores of a wave write one contiguous KB each
+            T* cp = out + (((((size_t)tile * nchunks_all + chunk) * 4 + wave) * 2 + blk) * 1024) + lane * 8;
+            *reinterpret_cast<u32x4*>(cp) = lo;
+            *reinterpret_cast<u32x4*>(cp + 512) = hi2;
+          } else if constexpr (!(ABL & 1)) {
             *reinterpret_cast<u32x4*>(op) = lo;
             *reinterpret_cast<u32x4*>(op + 8) = hi2;
           } else {
@@ -646,6 +651,7 @@ static hipError_t launch_dw_cfg(const IrbxArgs& a, hipStream_t s) {
         case 2: return go(&expand_dw_kernel<T, KS, DBUF, true, 2>);
         case 3: return go(&expand_dw_kernel<T, KS, DBUF, true, 3>);
         case 4: return go(&expand_dw_kernel<T, KS, DBUF, true, 4>);
+        case 16: return go(&expand_dw_kernel<T, KS, DBUF, true, 16>);
         case 8: return go(&expand_dw_kernel<T, KS, DBUF, true, 8>);
         case 11: return go(&expand_dw_kernel<T, KS, DBUF, true, 11>);
       }
