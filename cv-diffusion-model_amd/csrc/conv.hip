@@ -388,7 +388,7 @@ hipError_t launch_final_conv(int dtype, const FinalConvArgs& a, hipStream_t s) {
 // =============================================================================================
 // Implicit-GEMM 3x3 conv on MFMA.  MODE 0: stride 2, pad 1.  MODE 1: bilinear x2 (align_corners=False:
 // src = (dst+0.5)/2 - 0.5 clamped at 0, upper neighbour clamped at n-1) then stride 1, pad 1.
-template <typename T, int MODE, int TW, int BN, int WM, int WN>
+template <typename T, int MODE, int TW, int BN, int WM, int WN, bool RAGGED = false>
 __global__ void __launch_bounds__(WM* WN * 64) conv3x3_kernel(const Conv3Args a) {
   constexpr int NT = WM * WN * 64;
   constexpr int TH = 8, BM = TH * TW;
@@ -409,7 +409,9 @@ __global__ void __launch_bounds__(WM* WN * 64) conv3x3_kernel(const Conv3Args a)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
   const int Ho = MODE == 0 ? a.Hi / 2 : (MODE == 1 ? a.Hi * 2 : a.Hi), Wo = MODE == 0 ? a.Wi / 2 : (MODE == 1 ? a.Wi * 2 : a.Wi);
-  const int nb = a.Cout / BN, tiles_x = Wo / TW, tiles = tiles_x * (Ho / TH);
+  // ragged outputs (Ho % 8 or Wo % TW != 0: image sizes that are not a multiple of 64): edge tiles are partly empty -- pixels past
+  // the image are neither stored nor counted (the patch loader already reads everything outside as zero)
+  const int nb = a.Cout / BN, tiles_x = RAGGED ? (Wo + TW - 1) / TW : Wo / TW, tiles = tiles_x * (RAGGED ? (Ho + TH - 1) / TH : Ho / TH);
   int bid = blockIdx.x;
   const int ntile = bid % nb; bid /= nb;
   const int tile = bid % tiles, b = bid / tiles;
@@ -631,6 +633,7 @@ __global__ void __launch_bounds__(WM* WN * 64) conv3x3_kernel(const Conv3Args a)
 #pragma unroll
       for (int e = 0; e < VEC; ++e) v[e] = pc[e] + bias[e];
       const int oy = oy0 + row / TW, ox = ox0 + row % TW;
+      if (RAGGED && (oy >= Ho || ox >= Wo)) continue;
       vec_t ov = f32_to_vec<T>(v);
       st_vec<T>(outp + ((size_t)oy * Wo + ox) * a.Cout + n0 + cv * VEC, ov);
 #pragma unroll
@@ -670,9 +673,9 @@ __global__ void __launch_bounds__(WM* WN * 64) conv3x3_kernel(const Conv3Args a)
 }
 
 static int conv_tw(int Wo) { return (Wo % 16 == 0) ? 16 : 8; }
-int conv3x3_ntiles(int Ho, int Wo) { return (Ho / 8) * (Wo / conv_tw(Wo)); }
+int conv3x3_ntiles(int Ho, int Wo) { return ((Ho + 7) / 8) * ((Wo + conv_tw(Wo) - 1) / conv_tw(Wo)); }
 
-template <typename T, int MODE, int TW, int BN, int WM, int WN>
+template <typename T, int MODE, int TW, int BN, int WM, int WN, bool RAGGED = false>
 static hipError_t launch_conv_cfg(const Conv3Args& a, hipStream_t s) {
   constexpr int NT = WM * WN * 64, BM = 8 * TW, PITCH = TilePitch<T>::value;
   constexpr int PH = MODE == 0 ? 17 : 10, PW = MODE == 0 ? 2 * TW + 1 : TW + 2;
@@ -681,26 +684,35 @@ static hipError_t launch_conv_cfg(const Conv3Args& a, hipStream_t s) {
   constexpr size_t lds = tiles > ctile ? tiles : ctile;
   static bool attr_done = false;
   if (!attr_done && lds > 48 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_kernel<T, MODE, TW, BN, WM, WN>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_kernel<T, MODE, TW, BN, WM, WN, RAGGED>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     attr_done = true;
   }
   const int Ho = MODE == 0 ? a.Hi / 2 : (MODE == 1 ? a.Hi * 2 : a.Hi), Wo = MODE == 0 ? a.Wi / 2 : (MODE == 1 ? a.Wi * 2 : a.Wi);
-  const unsigned grid = (unsigned)(a.B * (Ho / 8) * (Wo / TW) * (a.Cout / BN));
+  const unsigned grid = (unsigned)(a.B * ((Ho + 7) / 8) * ((Wo + TW - 1) / TW) * (a.Cout / BN));
   static const std::string name = std::string("conv3x3_kernel<") + TypeName<T>::value + ", " + std::to_string(MODE) + ", " +
                                   std::to_string(TW) + ", " + std::to_string(BN) + ", " + std::to_string(WM) + ", " +
                                   std::to_string(WN) + ">";
   note_kernel(name.c_str());
-  hipLaunchKernelGGL((conv3x3_kernel<T, MODE, TW, BN, WM, WN>), dim3(grid), dim3(NT), lds, s, a);
+  hipLaunchKernelGGL((conv3x3_kernel<T, MODE, TW, BN, WM, WN, RAGGED>), dim3(grid), dim3(NT), lds, s, a);
   return hipGetLastError();
 }
 
 template <typename T, int MODE>
 static hipError_t launch_conv_t(const Conv3Args& a, hipStream_t s) {
   const int Ho = MODE == 0 ? a.Hi / 2 : (MODE == 1 ? a.Hi * 2 : a.Hi), Wo = MODE == 0 ? a.Wi / 2 : (MODE == 1 ? a.Wi * 2 : a.Wi);
-  if (Ho % 8 || Wo % 8 || a.Cin % 32 || a.Cout % 32 || (MODE == 0 && (a.Hi % 2 || a.Wi % 2))) return hipErrorInvalidValue;
+  if (Ho < 1 || Wo < 1 || a.Cin % 32 || a.Cout % 32 || (MODE == 0 && (a.Hi % 2 || a.Wi % 2))) return hipErrorInvalidValue;
   const int BN = (a.Cout % 128 == 0) ? 128 : ((a.Cout % 64 == 0) ? 64 : 32);
+  if (Ho % 8 || Wo % 8) {  // partly empty edge tiles: stride-2 convs onto maps that are not a multiple of 8 (image sizes % 64 != 0)
+    if constexpr (MODE == 0) {
+      if (BN == 128) return launch_conv_cfg<T, MODE, 8, 128, 2, 2, true>(a, s);
+      if (BN == 64) return launch_conv_cfg<T, MODE, 8, 64, 2, 2, true>(a, s);
+      return launch_conv_cfg<T, MODE, 8, 32, 2, 1, true>(a, s);
+    } else {
+      return hipErrorInvalidValue;
+    }
+  }
   if (conv_tw(Wo) == 16) {
     if (BN == 128) return launch_conv_cfg<T, MODE, 16, 128, 2, 2>(a, s);
     if (BN == 64) return launch_conv_cfg<T, MODE, 16, 64, 2, 2>(a, s);

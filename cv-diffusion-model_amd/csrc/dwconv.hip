@@ -37,8 +37,14 @@ constexpr int kDwPF = 4;  // rows of global loads kept in flight per thread
 // multiplies each output by the ReLU6 derivative of the forward pre-activation z = bx*bas + bab (bx = the tensor the
 // forward depthwise read) and writes per-8-row-segment partial sums (sum dz, sum dz*bx) for the GroupNorm backward,
 // in place of the SE pool partials.  The forward instantiation (BWD = false) compiles none of it.
+template <typename T, int TX, int PFV, bool BWD, bool S6, bool RAGGED>
+__device__ __forceinline__ void dw_body_impl(const DwArgs& a, const int TYL, const int dbg, const int swap);
 template <typename T, int TX, int PFV, bool BWD, bool S6 = false>
 __device__ __forceinline__ void dw_body(const DwArgs& a, const int TYL, const int dbg, const int swap) {
+  dw_body_impl<T, TX, PFV, BWD, S6, false>(a, TYL, dbg, swap);
+}
+template <typename T, int TX, int PFV, bool BWD, bool S6, bool RAGGED>
+__device__ __forceinline__ void dw_body_impl(const DwArgs& a, const int TYL, const int dbg, const int swap) {
   constexpr int NT = 8 * TX;
   constexpr int VEC = Elem<T>::VEC;
   constexpr int CC = 8 * VEC;  // channels per workgroup
@@ -49,7 +55,7 @@ __device__ __forceinline__ void dw_body(const DwArgs& a, const int TYL, const in
   __shared__ float red[(BWD ? 2 : 1) * 8 * (NT / 64) * CC];  // [8-row segment of the strip][wave][channel] (x2: BWD)
 
   const int tid = threadIdx.x, cl = tid & 7, xl = tid >> 3;
-  const int tiles_x = a.W / TX;
+  const int tiles_x = (a.W + TX - 1) / TX;
   // grid: x = channel chunk (fastest, so the workgroups that share a strip's DRAM pages are dispatched together when
   // g_dw_swap is set), y = strip; or x = strip, y = chunk
   const int tile_id = swap ? blockIdx.y : blockIdx.x, chunk_id = swap ? blockIdx.x : blockIdx.y;
@@ -60,6 +66,9 @@ __device__ __forceinline__ void dw_body(const DwArgs& a, const int TYL, const in
   const T* in = reinterpret_cast<const T*>(a.in) + (size_t)b * a.H * a.W * a.C + c0;
   T* out = reinterpret_cast<T*>(a.out) + (size_t)b * a.H * a.W * a.C + c0;
 
+  // ragged images (W % TX != 0 or H % TYL != 0: image sizes that are not a multiple of 64, forward only): columns / rows past the
+  // image are read as zero (the conv's padding) and neither stored nor pooled
+  const bool col_ok = RAGGED ? x0 + xl < a.W : true;
   // halo duty: threads 0..7 fetch column x0-1, threads 8..15 column x0+TX (their own channel lane)
   const bool is_halo = tid < 16;
   const int hx = tid < 8 ? x0 - 1 : x0 + TX;
@@ -84,7 +93,7 @@ __device__ __forceinline__ void dw_body(const DwArgs& a, const int TYL, const in
     const int gy = y0 - 1 + r;
     if (r < nrows && gy >= 0 && gy < a.H) {
       const T* row = in + (size_t)gy * a.W * a.C;
-      v = ld_vec<T>(row + (size_t)(x0 + xl) * a.C);
+      if (col_ok) v = ld_vec<T>(row + (size_t)(x0 + xl) * a.C);
       if (hx_ok) vh = ld_vec<T>(row + (size_t)hx * a.C);
     }
   };
@@ -155,7 +164,7 @@ __device__ __forceinline__ void dw_body(const DwArgs& a, const int TYL, const in
         }
       }
       vec_t* buf = ring[j & 1];  // r0 is a multiple of 12, so r & 1 == j & 1, r % 4 == j % 4, r % 3 == j % 3
-      buf[(xl + 1) * 8 + cl] = row_ok ? ((dbg & 2) ? pre[j % 4] : activate(pre[j % 4])) : zero;
+      buf[(xl + 1) * 8 + cl] = (row_ok && col_ok) ? ((dbg & 2) ? pre[j % 4] : activate(pre[j % 4])) : zero;
       if (is_halo) buf[hslot * 8 + cl] = (row_ok && hx_ok) ? activate(preh[j % 4]) : zero;
       issue(r + PF, pre[j % 4], preh[j % 4]);
       wg_barrier();
@@ -211,9 +220,11 @@ __device__ __forceinline__ void dw_body(const DwArgs& a, const int TYL, const in
           }
         } else {
           vec_t ov = f32_to_vec<T>(a2);
-          st_vec<T>(out + ((size_t)(y0 + r - 2) * a.W + x0 + xl) * a.C, ov);
+          if (!RAGGED || (col_ok && y0 + r - 2 < a.H)) {
+            st_vec<T>(out + ((size_t)(y0 + r - 2) * a.W + x0 + xl) * a.C, ov);
 #pragma unroll
-          for (int e = 0; e < VEC; ++e) psum[e] += (float)ov[e];
+            for (int e = 0; e < VEC; ++e) psum[e] += (float)ov[e];
+          }
           if ((a.pool || a.pool_tot) && ((r - 2) & 7) == 7)  // uniform: an 8-row pool segment is complete
             pool_segment_flush<VEC>(psum, red + (((r - 2) >> 3) * (NT / 64) + (tid >> 6)) * CC, tid & 63);
         }
@@ -247,6 +258,10 @@ __global__ void __launch_bounds__(8 * TX, (std::is_same<T, bf16_t>::value ? 3 : 
 dwconv3x3_kernel(const DwArgs a, const int TYL, const int dbg, const int swap) {
   dw_body<T, TX, PFV, false, S6>(a, TYL, dbg, swap);
 }
+template <typename T, int TX, int PFV, bool S6 = false>
+__global__ void __launch_bounds__(8 * TX) dwconv3x3_ragged_kernel(const DwArgs a, const int TYL, const int dbg, const int swap) {
+  dw_body_impl<T, TX, PFV, false, S6, true>(a, TYL, dbg, swap);  // partial strips at the right / bottom edge (W % 8 or H % 8 != 0)
+}
 template <typename T, int TX, int PFV>
 __global__ void __launch_bounds__(8 * TX) dwconv3x3_bwd_kernel(const DwArgs a, const int TYL, const int swap) {
   dw_body<T, TX, PFV, true>(a, TYL, 0, swap);
@@ -256,30 +271,49 @@ static int g_dw_swap = 0;
 void dwconv_swap(int v) { g_dw_swap = v; }
 static int g_dw_dbg = 0;
 void dwconv_debug(int v) { g_dw_dbg = v; }  // bits 0-1: timing ablations
-static int dw_tx(int W) { return (W % 32 == 0) ? 32 : ((W % 16 == 0) ? 16 : 8); }
+static int dw_tx(int W) { return (W % 32 == 0) ? 32 : ((W % 16 == 0) ? 16 : (W % 8 == 0 ? 8 : (W > 16 ? 32 : 16))); }
 // Strip height: as tall as possible (fewer halo rows) while the launch still has >= 1024 workgroups to
 // fill 256 CUs; small batches get shorter strips.  `chunks` = C / channels per WG.  The pool slab does
 // not depend on the choice (8-row segments), so results are bitwise independent of the batch size.
 int dw_pick_tyl(int B, int H, int W, int chunks) {
-  const int tiles_x = W / dw_tx(W);
+  if (H % 8) return 8;  // ragged bottom edge: 8-row strips, the last one partial
+  const int tiles_x = (W + dw_tx(W) - 1) / dw_tx(W);
   const int cand[4] = {64, 32, 16, 8};
   for (int i = 0; i < 4; ++i)
     if (H % cand[i] == 0 && (long)tiles_x * (H / cand[i]) * chunks * B >= 1024) return cand[i];
   return 8;
 }
-int dwconv_ntiles(int H, int W) { return (H / kPoolSegRows) * (W / dw_tx(W)); }
+int dwconv_ntiles(int H, int W) { return ((H + kPoolSegRows - 1) / kPoolSegRows) * ((W + dw_tx(W) - 1) / dw_tx(W)); }
 
 template <typename T>
 static hipError_t launch_dw_t(const DwArgs& a, hipStream_t s) {
   constexpr int CC = 8 * Elem<T>::VEC;
-  if (a.C % CC || a.H % 8 || a.W % 8) return hipErrorInvalidValue;
+  const bool ragged = a.H % 8 || a.W % 8;  // forward only: partial strips at the right / bottom edge
+  if (a.C % CC || a.H < 1 || a.W < 1 || (ragged && (a.bx || a.pool))) return hipErrorInvalidValue;
   const int tx = dw_tx(a.W), tyl = dw_pick_tyl(a.B, a.H, a.W, a.C / CC);
-  dim3 grid((a.W / tx) * (a.H / tyl), a.C / CC, a.B);
-  if (g_dw_swap) grid = dim3(a.C / CC, (a.W / tx) * (a.H / tyl), a.B);
+  const int tiles = ((a.W + tx - 1) / tx) * ((a.H + tyl - 1) / tyl);
+  dim3 grid(tiles, a.C / CC, a.B);
+  if (g_dw_swap) grid = dim3(a.C / CC, tiles, a.B);
   static const std::string names[3] = {std::string("dwconv3x3_kernel<") + TypeName<T>::value + ", 32, 4>",
                                        std::string("dwconv3x3_kernel<") + TypeName<T>::value + ", 16, 4>",
                                        std::string("dwconv3x3_kernel<") + TypeName<T>::value + ", 8, 4>"};
   note_kernel(names[tx == 32 ? 0 : (tx == 16 ? 1 : 2)].c_str());
+  if (ragged) {  // forward only (checked above); TX is 16 or 32 here
+    note_kernel("dwconv3x3_ragged_kernel");
+    if constexpr (sizeof(T) == 2) {
+      if (a.s6) {
+        if (a.no_act) return hipErrorInvalidValue;
+        if (tx == 32) hipLaunchKernelGGL((dwconv3x3_ragged_kernel<T, 32, kDwPF, true>), grid, dim3(256), 0, s, a, tyl, 0, g_dw_swap);
+        else hipLaunchKernelGGL((dwconv3x3_ragged_kernel<T, 16, kDwPF, true>), grid, dim3(128), 0, s, a, tyl, 0, g_dw_swap);
+        return hipGetLastError();
+      }
+    } else if (a.s6) {
+      return hipErrorInvalidValue;
+    }
+    if (tx == 32) hipLaunchKernelGGL((dwconv3x3_ragged_kernel<T, 32, kDwPF>), grid, dim3(256), 0, s, a, tyl, 0, g_dw_swap);
+    else hipLaunchKernelGGL((dwconv3x3_ragged_kernel<T, 16, kDwPF>), grid, dim3(128), 0, s, a, tyl, 0, g_dw_swap);
+    return hipGetLastError();
+  }
   if (a.bx) {  // backward instantiation
     if (!a.bas || !a.bab || !a.bslab || a.pool) return hipErrorInvalidValue;
     if (tx == 32) hipLaunchKernelGGL((dwconv3x3_bwd_kernel<T, 32, kDwPF>), grid, dim3(256), 0, s, a, tyl, g_dw_swap);

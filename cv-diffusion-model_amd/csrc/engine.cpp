@@ -413,7 +413,9 @@ int build_unet(llie_ctx* c) {
       in_ch = out;
     }
   }
-  if (g.base_channels % 2 || g.image_size % 64 || g.image_size < 64) return LLIE_ERR_SHAPE;
+  // three stride-2 levels; the kernels' tiles have ragged edges down to 4-pixel granularity at the lowest level: any multiple
+  // of 32 (the reference accepts any multiple of 8).  Training needs multiples of 64 (checked in the training entry points).
+  if (g.base_channels % 2 || g.image_size % 32 || g.image_size < 64) return LLIE_ERR_SHAPE;
   if (g.in_channels < 2 || g.in_channels > 8 || g.out_channels > 4) return LLIE_ERR_SHAPE;
 
   c->t_w1 = b.reserve((size_t)T * g.base_channels * 4);
@@ -664,7 +666,7 @@ struct Run {
                         irbx_supported(dt, w.cin, x0.C, w.hid, H, W);
     // K1: expand with norm1 + ReLU6 prologue
     Tens h1;
-    h1.C = w.hid; h1.Cr = w.hid_r; h1.H = H; h1.W = W; h1.ntiles = fusedx ? P / irbx_stats_rows(P) : P / BM; h1.valid = true;
+    h1.C = w.hid; h1.Cr = w.hid_r; h1.H = H; h1.W = W; h1.ntiles = fusedx ? P / irbx_stats_rows(P) : pw_gemm_ntiles(P); h1.valid = true;
     h1.off = fusedx ? 0 : ar->alloc((size_t)B * P * w.hid * es());
     h1.slab = ar->alloc((size_t)B * h1.ntiles * 2 * w.hid * 4);
     IrbxArgs xa{};
@@ -738,7 +740,7 @@ struct Run {
     if (!ztot) rel(pool);
     rel(sehid); rel(semean);
     // K3: project with SE gate prologue (+ skip conv as extra K segments, or identity residual)
-    Tens y = new_tens(w.cout, H, W, P / BM, w.cout_r);
+    Tens y = new_tens(w.cout, H, W, pw_gemm_ntiles(P), w.cout_r);
     if (!dry) {
       GemmArgs g{};
       g.seg[0] = GemmSeg{p(h2), w.hid, p<float>(gate), nullptr, w.hid, ACT_NONE};
@@ -795,7 +797,7 @@ struct Run {
       timed(LLIE_K_OTHER, (int64_t)M * 2 * w.inner * (int64_t)es(), [&] { return launch_linattn_out(dt, a, s); }, "linattn_out_kernel");
     }
     rel(qkv); rel(kv);
-    Tens tmp = new_tens(x.C, H, W, N / BM);
+    Tens tmp = new_tens(x.C, H, W, pw_gemm_ntiles(N));
     if (!dry) {
       GemmArgs g{};
       g.seg[0] = GemmSeg{p(ao), w.inner, nullptr, nullptr, 0, ACT_NONE};
@@ -806,7 +808,7 @@ struct Run {
     rel(ao);
     size_t as2, ab2;
     gn(tmp, nullptr, w.n2g, w.n2b, nullptr, 0, as2, ab2, &rec.n2);
-    Tens y = new_tens(x.C, H, W, N / kAffineTileRows);
+    Tens y = new_tens(x.C, H, W, (N + kAffineTileRows - 1) / kAffineTileRows);
     if (!dry) {
       AffineAddArgs a{};
       a.x = p(tmp.off); a.as = p<float>(as2); a.ab = p<float>(ab2); a.res = p(x.off); a.y = p(y.off);
@@ -1823,6 +1825,7 @@ int64_t llie_param_grad_offset(const llie_ctx* c, int i) {
 int64_t llie_train_workspace_bytes(llie_ctx* c, int batch, int height, int width) {
   if (!c || batch <= 0) return LLIE_ERR_ARG;
   if (c->padded) { set_err("the unpinned variants (tiny / base, zero-padded channels) are inference-only"); return LLIE_ERR_CONFIG; }
+  if (c->cfg.kind == LLIE_UNET && c->cfg.image_size % 64) { set_err("training needs an image_size that is a multiple of 64 (inference: 32)"); return LLIE_ERR_SHAPE; }
   Arena ar((size_t)1 << 46);
   Tape tape;
   Run r{c, &ar, nullptr, nullptr, true, batch, c->dt};
@@ -1845,6 +1848,7 @@ int llie_unet_train_forward(llie_ctx* c, const float* lat, const float* cond, co
                             void* ws, int64_t ws_bytes, llie_stream stream) {
   if (!c || !lat || !cond || !t || !eps || !ws || batch <= 0 || c->cfg.kind != LLIE_UNET) return LLIE_ERR_ARG;
   if (c->padded) { set_err("the unpinned variants (tiny / base, zero-padded channels) are inference-only"); return LLIE_ERR_CONFIG; }
+  if (c->cfg.image_size % 64) { set_err("training needs an image_size that is a multiple of 64 (inference: 32)"); return LLIE_ERR_SHAPE; }
   if (!c->blob) { set_err("no HIP device"); return LLIE_ERR_NO_DEVICE; }
   int rc = check_loaded(c);
   if (rc) return rc;

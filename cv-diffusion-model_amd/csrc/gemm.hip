@@ -19,9 +19,11 @@
 namespace llie {
 
 // ---- epilogue shared by the GEMM kernels: accumulators -> LDS (fp32) -> 16-byte row vectors (+bias, +residual, stats) -> HBM.
-template <typename T, int BM, int BN, int WM, int WN>
+// RAGGED (64-row tiles only): the tile is the last of its image and only its first `vrows` rows exist (P % 64 != 0: image
+// sizes that are not a multiple of 64) -- rows beyond are neither stored nor counted in the statistics.
+template <typename T, int BM, int BN, int WM, int WN, bool RAGGED = false>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[BM / (WM * 32)][BN / (WN * 32)], unsigned char* smem,
-                                              int m0, int n0, int img) {
+                                              int m0, int n0, int img, int vrows = BM) {
   constexpr int NT = WM * WN * 64;
   constexpr int VEC = Elem<T>::VEC;
   constexpr int MI = BM / (WM * 32), NI = BN / (WN * 32);
@@ -71,6 +73,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[B
       if (SROWS % RPP != 0 && srow >= SROWS) break;
       const int grp = SG == 1 ? 0 : (it * RPP) >> 5;     // wave row == statistic group (static after unrolling)
       const int row = ((srow >> 5) * MI + pi) * 32 + (srow & 31);  // row inside the BM tile
+      if (RAGGED && row >= vrows) continue;
       float v[VEC];
       const float* pc = sC + srow * CP + cv * VEC;
 #pragma unroll
@@ -108,7 +111,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[B
   if (g.stats) {
     float* red = sC + SROWS * CP;  // [waves][2][BN]
     constexpr int NW = NT / 64;
-    const int ntiles = g.P / G;
+    const int ntiles = RAGGED ? (g.P + G - 1) / G : g.P / G;
 #pragma unroll
     for (int q = 0; q < SG; ++q) {
       // lanes with equal cv differ in lane bits >= log2(VR)
@@ -128,7 +131,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[B
         }
       }
       wg_barrier();
-      const int tile = (m0 % g.P) / G + q;
+      const int tile = (m0 - img * g.P) / G + q;
       for (int i = tid; i < 2 * BN; i += NT) {
         const int which = i / BN, c = i % BN;
         float t = 0.f;
@@ -142,8 +145,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[B
 
 // STAMP: diagnostic build (llie_tune("gemm_stamp", 1)): s_memtime per wave at kernel start / after the K loop / at the end,
 // summed into g.stamps[0..2] = {K loop, epilogue, waves}; never used in production.
-template <typename T, int BM, int BN, int WM, int WN, int BK, bool STAMP = false>
+template <typename T, int BM, int BN, int WM, int WN, int BK, bool STAMP = false, bool RAGGED = false>
 __global__ void __launch_bounds__(WM* WN * 64) pw_gemm_kernel(const GemmArgs g) {
+  static_assert(!RAGGED || BM == 64, "ragged images use the 64-row tiles");
   unsigned long long t_start = 0, t_loop = 0;
   if constexpr (STAMP) t_start = __builtin_amdgcn_s_memtime();
   constexpr int NT = WM * WN * 64;
@@ -168,13 +172,16 @@ __global__ void __launch_bounds__(WM* WN * 64) pw_gemm_kernel(const GemmArgs g) 
   // n fastest: neighbours share the A tile.  Workgroups are dealt round-robin to the 8 XCDs (one L2 each), so with more than
   // one N tile the tiles of an M tile are kept on one XCD's L2 (dbg bit 4 = plain order, for A/B runs: up to 14 % faster on the 1024-pixel layers)
   int mt = blockIdx.x / nb, ntile = blockIdx.x % nb;
-  if (nb > 1 && (g.M / BM) % 8 == 0 && !(g.dbg & 16)) {
+  const int tpi = RAGGED ? (g.P + BM - 1) / BM : g.P / BM;  // M tiles per image
+  const int mtiles = (g.M / g.P) * tpi;
+  if (nb > 1 && mtiles % 8 == 0 && !(g.dbg & 16)) {
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     mt = (slot / nb) * 8 + xcd;
     ntile = slot % nb;
   }
-  const int m0 = mt * BM, n0 = ntile * BN;
-  const int img = m0 / g.P;
+  const int img = mt / tpi, r0 = (mt - img * tpi) * BM;
+  const int m0 = img * g.P + r0, n0 = ntile * BN;
+  const int vrows = RAGGED ? (g.P - r0 < BM ? g.P - r0 : BM) : BM;  // rows of this tile that exist
   const int kv = (tid % VPR) * VEC;  // this thread's k offset inside every chunk
 
   f32x16 acc[MI][NI];
@@ -201,7 +208,8 @@ __global__ void __launch_bounds__(WM* WN * 64) pw_gemm_kernel(const GemmArgs g) 
     for (int i = 0; i < A_PER; ++i) {
       const int idx = tid + i * NT;
       if (A_VECS % NT == 0 || idx < A_VECS) {
-        const int row = idx / VPR;
+        int row = idx / VPR;
+        if (RAGGED) row = row < vrows ? row : vrows - 1;  // rows past the image: re-read the last one (never stored or counted)
         ra[i] = ld_vec<T>(abase + (size_t)(m0 + row) * sg.ch + cl + kv);
       }
     }
@@ -314,7 +322,7 @@ __global__ void __launch_bounds__(WM* WN * 64) pw_gemm_kernel(const GemmArgs g) 
   }
 
   if constexpr (STAMP) t_loop = __builtin_amdgcn_s_memtime();
-  gemm_epilogue<T, BM, BN, WM, WN>(g, acc, smem, m0, n0, img);
+  gemm_epilogue<T, BM, BN, WM, WN, RAGGED>(g, acc, smem, m0, n0, img, vrows);
   if constexpr (STAMP) {
     if (g.stamps && (threadIdx.x & 63) == 0) {  // one (K loop, epilogue) pair per wave, no atomics: the stamped launch keeps its timing
       const unsigned long long t_end = __builtin_amdgcn_s_memtime();
@@ -349,7 +357,7 @@ hipError_t pw_gemm_stamp_fetch(double* out3) {  // mean s_memtime ticks per wave
   return hipSuccess;
 }
 
-template <typename T, int BM, int BN, int WM, int WN, int BK>
+template <typename T, int BM, int BN, int WM, int WN, int BK, bool RAGGED = false>
 static hipError_t launch_cfg(const GemmArgs& a, hipStream_t s) {
   constexpr int NT = WM * WN * 64;
   constexpr int PITCH = BK + Elem<T>::VEC;
@@ -358,12 +366,12 @@ static hipError_t launch_cfg(const GemmArgs& a, hipStream_t s) {
   constexpr size_t lds = tiles > ctile ? tiles : ctile;
   static bool attr_done = false;
   if (!attr_done && lds > 48 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pw_gemm_kernel<T, BM, BN, WM, WN, BK>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pw_gemm_kernel<T, BM, BN, WM, WN, BK, false, RAGGED>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     attr_done = true;
   }
-  const unsigned grid = (unsigned)((a.M / BM) * (a.N / BN));
+  const unsigned grid = (unsigned)((a.M / a.P) * ((a.P + BM - 1) / BM) * (a.N / BN));  // == (M / BM) * (N / BN) unless RAGGED
   if constexpr (sizeof(T) == 2 && BM == 128) {
     if (g_gemm_stamp) {
       if (hipError_t e = stamp_buffer((size_t)grid * (NT / 64)); e != hipSuccess) return e;
@@ -379,11 +387,12 @@ static hipError_t launch_cfg(const GemmArgs& a, hipStream_t s) {
                                   std::to_string(BN) + ", " + std::to_string(WM) + ", " + std::to_string(WN) + ", " +
                                   std::to_string(BK) + ">";
   note_kernel(name.c_str());
-  hipLaunchKernelGGL((pw_gemm_kernel<T, BM, BN, WM, WN, BK>), dim3(grid), dim3(NT), lds, s, a);
+  hipLaunchKernelGGL((pw_gemm_kernel<T, BM, BN, WM, WN, BK, false, RAGGED>), dim3(grid), dim3(NT), lds, s, a);
   return hipGetLastError();
 }
 
 int pw_gemm_tile_rows(int P) { return (P % 128 == 0) ? 128 : 64; }
+int pw_gemm_ntiles(int P) { const int bm = pw_gemm_tile_rows(P); return (P + bm - 1) / bm; }  // statistics partials per image
 
 // tuning knobs for tools/gpu_tune.py (0 = automatic)
 static int g_force_bk = 0, g_bk128 = 1024;
@@ -412,6 +421,11 @@ static hipError_t launch_t(const GemmArgs& a, hipStream_t s) {
     if (BN == 64) return k64 ? launch_cfg<T, 128, 64, 2, 2, 64>(a, s) : launch_cfg<T, 128, 64, 2, 2, 32>(a, s);
     return k64 ? launch_cfg<T, 128, 32, 4, 1, 64>(a, s) : launch_cfg<T, 128, 32, 4, 1, 32>(a, s);
   }
+  if (a.P % 64) {  // the last 64-row tile of every image is partly empty (image sizes that are not a multiple of 64)
+    if (BN == 128) return launch_cfg<T, 64, 128, 2, 2, 32, true>(a, s);
+    if (BN == 64) return launch_cfg<T, 64, 64, 2, 2, 32, true>(a, s);
+    return launch_cfg<T, 64, 32, 2, 1, 32, true>(a, s);
+  }
   if (BN == 128) return launch_cfg<T, 64, 128, 2, 2, 32>(a, s);
   if (BN == 64) return launch_cfg<T, 64, 64, 2, 2, 32>(a, s);
   return launch_cfg<T, 64, 32, 2, 1, 32>(a, s);
@@ -426,7 +440,7 @@ hipError_t launch_pw_gemm(int dtype, const GemmArgs& a0, hipStream_t s) {
   if (a.nostore && (!a.stats || a.res)) return hipErrorInvalidValue;
   // host-side shape contract of the kernel (checked before any launch: an out-of-contract shape
   // would index out of bounds on the device)
-  if (a.nseg < 1 || a.nseg > 3 || a.N % 32 || a.K % 32 || a.P % 64 || a.M % a.P) return hipErrorInvalidValue;
+  if (a.nseg < 1 || a.nseg > 3 || a.N % 32 || a.K % 32 || a.P % 16 || a.P < 16 || a.M % a.P) return hipErrorInvalidValue;
   int k = 0;
   for (int i = 0; i < a.nseg; ++i) {
     if (a.seg[i].ch % 32 || a.seg[i].ch <= 0 || !a.seg[i].ptr) return hipErrorInvalidValue;

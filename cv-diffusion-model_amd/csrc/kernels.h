@@ -56,7 +56,8 @@ struct GemmArgs {
 void pw_gemm_stamp(int v);
 hipError_t pw_gemm_stamp_fetch(double* out3);
 hipError_t launch_pw_gemm(int dtype, const GemmArgs& a, hipStream_t s);
-int pw_gemm_tile_rows(int P);  // BM used for a given P (stats slab tiles = P / BM)
+int pw_gemm_tile_rows(int P);  // BM used for a given P
+int pw_gemm_ntiles(int P);     // stats slab tiles per image = ceil(P / BM)
 void pw_gemm_force_bk(int bk);  // tuning knob (0 = automatic)
 void pw_gemm_bk128(int max_grid);  // 128-wide K chunks for launches of up to this many workgroups (0 = never)
 void pw_gemm_debug(int v);      // timing ablations; results are wrong when non-zero

@@ -429,9 +429,10 @@ __global__ void __launch_bounds__(256) linattn_kv_kernel(const AttnArgs a) {
   for (int n0 = sp * span; n0 < (sp + 1) * span; n0 += CH) {
     for (int i = tid; i < CH * 32; i += 256) {
       const int n = i >> 5, c = i & 31;
-      const T* row = base + (size_t)(n0 + n) * ld;
-      sk[n][c] = phi((float)row[inner + h * 32 + c]);
-      sv[n][c] = (float)row[2 * inner + h * 32 + c];
+      const bool ok = n0 + n < (sp + 1) * span;  // last chunk of a span that is not a multiple of 64 positions: zero contribution
+      const T* row = base + (size_t)(ok ? n0 + n : 0) * ld;
+      sk[n][c] = ok ? phi((float)row[inner + h * 32 + c]) : 0.f;
+      sv[n][c] = ok ? (float)row[2 * inner + h * 32 + c] : 0.f;
     }
     wg_barrier();
 #pragma unroll 8
@@ -496,7 +497,7 @@ int linattn_nsplit(int N) {
   return ns;
 }
 hipError_t launch_linattn_kv(int dtype, const AttnArgs& a, hipStream_t s) {
-  if (a.nsplit < 1 || a.N % (64 * a.nsplit)) return hipErrorInvalidValue;
+  if (a.nsplit < 1 || a.N % a.nsplit || (a.nsplit > 1 && a.N % (64 * a.nsplit))) return hipErrorInvalidValue;
   dim3 grid(a.heads, a.B, a.nsplit);
   switch (dtype) {
     case 0: hipLaunchKernelGGL(linattn_kv_kernel<float>, grid, dim3(256), 0, s, a); break;
@@ -525,8 +526,11 @@ __global__ void __launch_bounds__(256) affine_add_kernel(const AffineAddArgs a) 
   constexpr int VEC = Elem<T>::VEC;
   extern __shared__ float red[];  // [4 waves][2][C]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int m0 = blockIdx.x * kAffineTileRows;
-  const int img = m0 / a.P;
+  // tiles never straddle images: ceil(P / 64) tiles per image, the last one partial when P is not a multiple of 64
+  const int tpi = (a.P + kAffineTileRows - 1) / kAffineTileRows;
+  const int img = blockIdx.x / tpi, r0 = (blockIdx.x - img * tpi) * kAffineTileRows;
+  const int m0 = img * a.P + r0;
+  const int vrows = a.P - r0 < kAffineTileRows ? a.P - r0 : kAffineTileRows;
   const int vpr = a.C / VEC;  // vectors per row
   const T* x = reinterpret_cast<const T*>(a.x);
   const T* res = reinterpret_cast<const T*>(a.res);
@@ -544,7 +548,7 @@ __global__ void __launch_bounds__(256) affine_add_kernel(const AffineAddArgs a) 
       s1[e] = 0.f;
       s2[e] = 0.f;
     }
-    for (int r = wave; r < kAffineTileRows; r += 4) {
+    for (int r = wave; r < vrows; r += 4) {
       const size_t o = (size_t)(m0 + r) * a.C + v0 * VEC;
       float f[VEC];
       ld_f32<T>(x + o, f);
@@ -575,7 +579,7 @@ __global__ void __launch_bounds__(256) affine_add_kernel(const AffineAddArgs a) 
   }
   if (a.stats) {
     wg_barrier();
-    const int ntiles = a.P / kAffineTileRows, tile = (m0 % a.P) / kAffineTileRows;
+    const int ntiles = tpi, tile = r0 / kAffineTileRows;
     for (int i = tid; i < 2 * a.C; i += 256) {
       const int which = i / a.C, c = i % a.C;
       const float t = red[(0 * 2 + which) * a.C + c] + red[(1 * 2 + which) * a.C + c] + red[(2 * 2 + which) * a.C + c] +
@@ -585,8 +589,8 @@ __global__ void __launch_bounds__(256) affine_add_kernel(const AffineAddArgs a) 
   }
 }
 hipError_t launch_affine_add(int dtype, const AffineAddArgs& a, hipStream_t s) {
-  if (a.P % kAffineTileRows || a.M % a.P || a.C % 8) return hipErrorInvalidValue;
-  dim3 grid(a.M / kAffineTileRows);
+  if (a.P < 1 || a.M % a.P || a.C % 8) return hipErrorInvalidValue;
+  dim3 grid((a.M / a.P) * ((a.P + kAffineTileRows - 1) / kAffineTileRows));
   const size_t lds = (size_t)8 * a.C * 4;
   switch (dtype) {
     case 0: hipLaunchKernelGGL(affine_add_kernel<float>, grid, dim3(256), lds, s, a); break;

@@ -177,6 +177,42 @@ def test_base128_eight_steps_fp16_vs_oracle(dev):
         m.compute_dtype = None
 
 
+@pytest.mark.parametrize("size,batch", [(96, 3), (160, 1), (224, 1)])
+def test_image_sizes_that_are_not_multiples_of_64(dev, size, batch):
+    """The reference builds any image_size its three stride-2 convolutions accept (efficient_unet.py:403-530, CLI
+    `--image_size`, scripts/inference.py:30-62).  The engine takes every multiple of 32 from 64 on: at the lowest resolution (12 x 12,
+    20 x 20, 28 x 28) the GEMM / depthwise / stride-2 conv / attention tiles are partly empty.  fp32 engine vs oracle <= 1e-3
+    on the pre-clamp latents, fp16 by PSNR, sub-batch rows bit-equal."""
+    m, sd, spec = model("small", size, dev)
+    gen = torch.Generator().manual_seed(size)
+    low = torch.rand(batch, 3, size, size, generator=gen) * 2 - 1
+    noise = oracle.draw_noise(batch, size, 4, seed=size + 1)
+    ref = oracle.enhance_ref(sd, spec, low, 4, noise)
+    m.compute_dtype = None
+    out = m.enhance(low.to(dev), 4, noise=torch.stack(noise), return_intermediate=True)
+    err = max(max_abs(a.cpu(), b) for a, b in zip(out.intermediate, ref["intermediate"]))
+    print(f"small@{size} B={batch} fp32: max-abs latent error {err:.2e}")
+    assert err < 1e-3
+    m.compute_dtype = "fp16"
+    try:
+        nz = torch.stack(noise).to(dev)
+        o = m.enhance(low.to(dev), 4, noise=nz, return_intermediate=True)
+        p = psnr01(o.enhanced.cpu(), ref["enhanced"])
+        print(f"small@{size} fp16: PSNR {p:.1f} dB vs oracle")
+        assert p > 40.0
+        one = m.enhance(low[:1].to(dev), 4, noise=nz[:, :1], return_intermediate=True)
+        assert torch.equal(o.intermediate[-1][:1], one.intermediate[-1])
+    finally:
+        m.compute_dtype = None
+
+
+def test_unsupported_image_sizes_are_refused(dev):
+    for size in (72, 100, 32):
+        with pytest.raises(ValueError):
+            mm = M.LowLightDiffusion(unet_variant="small", image_size=size).to(dev)
+            mm.enhance(torch.zeros(1, 3, size, size, device=dev), 4)
+
+
 def test_full_size_properties_base256_b32_n8_fp16(dev):
     """BASELINE config 3's per-GPU shape (base, 256x256, 32 images per GPU, 8 steps, fp16)."""
     m, sd, spec = model("base", 256, dev)
