@@ -3,7 +3,8 @@ C ABI to be reachable "via PyTorch-ROCm custom ops").  The operators are thin: t
 call the same ctypes path as the module methods, so eager code, `torch.library.opcheck`-style tooling and exporters
 see named ops with fake (meta) implementations instead of opaque Python.
 
-    mid = register_model(model)                       # model: LowLightDiffusion (or anything with .unet / .enhance)
+    mid = register_model(model)                       # model: LowLightDiffusion (or anything with .unet / .enhance);
+                                                      # register_model(model, key=7) pins the slot for exported graphs
     y   = torch.ops.llie.enhance(mid, low_light, noise, 4)          # [B,3,S,S] -> [B,3,S,S]
     eps = torch.ops.llie.unet_forward(mid, latents, cond, t)        # noise prediction, per-sample timesteps
     x   = torch.ops.llie.lcm_step(model_output, sample, noise, sqrt_a_t, sqrt_b_t, sqrt_a_prev, sqrt_b_prev, last, vpred)
@@ -13,7 +14,7 @@ No CPU implementation is registered: on CPU tensors the ops raise, like the modu
 from __future__ import annotations
 
 import weakref
-from typing import Dict
+from typing import Dict, Optional
 
 import torch
 
@@ -22,11 +23,28 @@ from . import _native as N
 _MODELS: Dict[int, "weakref.ReferenceType"] = {}
 
 
-def register_model(model) -> int:
-    """Make `model` addressable from the custom ops; returns its id (the registry holds a weak reference)."""
-    mid = id(model)
-    _MODELS[mid] = weakref.ref(model)
-    return mid
+_NEXT_KEY = [1]
+
+
+def register_model(model, key: Optional[int] = None) -> int:
+    """Make `model` addressable from the custom ops and return the integer the ops take as `model_id` (the registry holds a
+    weak reference).  `key` chooses that integer: a graph exported with `model_id = 7` baked in as a constant runs in another
+    process after `register_model(its_model, key=7)` -- the id is a slot of the caller's choosing, not the address of a
+    Python object.  Without `key` the next free small integer is used; registering the same model again returns its slot."""
+    if key is None:
+        for k, ref in _MODELS.items():
+            if ref() is model:
+                return k
+        while _NEXT_KEY[0] in _MODELS and _MODELS[_NEXT_KEY[0]]() is not None:
+            _NEXT_KEY[0] += 1
+        key = _NEXT_KEY[0]
+        _NEXT_KEY[0] += 1
+    key = int(key)
+    cur = _MODELS.get(key)
+    if cur is not None and cur() is not None and cur() is not model:
+        raise ValueError(f"llie: slot {key} already holds another live model")
+    _MODELS[key] = weakref.ref(model)
+    return key
 
 
 def _model(mid: int):

@@ -371,3 +371,21 @@ def test_bench_kernel_class_mapping():
     assert b.pmc_lookup(table, "pw_gemm_kernel<_Float16, 128, 128, 2, 2, 128>") == 2
     assert b.pmc_lookup(table, "expand_dw_kernel<_Float16, 2, 0>") == 3
     assert b.pmc_lookup(table, "expand_dw_kernel<_Float16, 4, 0>") is None
+
+
+def test_custom_op_registry_slots():
+    """`register_model` hands out stable small integers (or the caller's `key`), not `id(model)`: an exported graph that
+    bakes the integer in can be re-bound in another process."""
+    class Dummy:
+        pass
+    a, b = Dummy(), Dummy()
+    ka = M.register_model(a)
+    assert ka == M.register_model(a) and ka < 1 << 20        # same model -> same slot; not an address
+    kb = M.register_model(b, key=777)
+    assert kb == 777 and M.register_model(b) == 777
+    with pytest.raises(ValueError):
+        M.register_model(a, key=777)                         # slot taken by a live model
+    del b
+    import gc
+    gc.collect()
+    assert M.register_model(a, key=777) == 777               # a dead slot can be reused
