@@ -25,7 +25,7 @@ __global__ void __launch_bounds__(256) init_conv_kernel(const InitConvArgs a) {
   __shared__ float patch[MAXC][18][19];
   __shared__ float red[4][2][32];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int tiles_x = a.W / 16;
+  const int tiles_x = (a.W + 15) / 16;  // edge tiles may be partly empty (image sizes that are not a multiple of 16)
   const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x, b = blockIdx.y;
   const int x0 = tx * 16, y0 = ty * 16;
   const int Cin = a.c0 + a.c1;
@@ -43,9 +43,10 @@ __global__ void __launch_bounds__(256) init_conv_kernel(const InitConvArgs a) {
   }
   wg_barrier();
   const int py = tid >> 4, px = tid & 15;
+  const bool ok = y0 + py < a.H && x0 + px < a.W;
   const float* __restrict__ w = a.w;
   T* out = reinterpret_cast<T*>(a.out) + (((size_t)b * a.H + y0 + py) * a.W + x0 + px) * a.Cout;
-  const int ntiles = tiles_x * (a.H / 16);
+  const int ntiles = tiles_x * ((a.H + 15) / 16);
   for (int oc0 = 0; oc0 < a.Cout; oc0 += 32) {
     float acc[32];
 #pragma unroll
@@ -63,9 +64,9 @@ __global__ void __launch_bounds__(256) init_conv_kernel(const InitConvArgs a) {
 #pragma unroll
     for (int o = 0; o < 32; o += VEC) {
       typename Elem<T>::vec_t ov = f32_to_vec<T>(acc + o);
-      st_vec<T>(out + oc0 + o, ov);
+      if (ok) st_vec<T>(out + oc0 + o, ov);
 #pragma unroll
-      for (int e = 0; e < VEC; ++e) q[o + e] = (float)ov[e];
+      for (int e = 0; e < VEC; ++e) q[o + e] = ok ? (float)ov[e] : 0.f;
     }
     if (a.stats) {
 #pragma unroll
@@ -101,7 +102,7 @@ __global__ void __launch_bounds__(256) init_conv_mfma_kernel(const InitConvArgs 
   __shared__ float ctile[4][32 * 33];
   __shared__ float red[4][2][32];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int tiles_x = a.W / TW;
+  const int tiles_x = (a.W + TW - 1) / TW;  // the last tile of a row may be partly empty (W % 32 != 0)
   const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x, b = blockIdx.y;
   const int x0 = tx * TW, y0 = ty * TH;
   const int Cin = a.c0 + a.c1;
@@ -150,7 +151,8 @@ __global__ void __launch_bounds__(256) init_conv_mfma_kernel(const InitConvArgs 
       // D[pixel (rows in registers)][channel = r]: + bias, round, stats, then transpose through LDS
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
-        const float v = (float)(T)(acc[q] + bias);
+        float v = (float)(T)(acc[q] + bias);
+        if (x0 + mfma_row(q, lane) >= a.W) v = 0.f;  // pixel past the image (never stored either)
         s1 += v;
         s2 += v * v;
         ct[mfma_row(q, lane) * 33 + r] = v;
@@ -165,8 +167,10 @@ __global__ void __launch_bounds__(256) init_conv_mfma_kernel(const InitConvArgs 
         for (int e = 0; e < 16; ++e) f[e] = ct[p * 33 + half * 16 + e];
         const int oy = y0 + g, ox = x0 + p;
         T* dst = out + ((size_t)oy * a.W + ox) * a.Cout + oc0 + half * 16;
-        st_vec<T>(dst, f32_to_vec<T>(f));
-        st_vec<T>(dst + 8, f32_to_vec<T>(f + 8));
+        if (ox < a.W) {
+          st_vec<T>(dst, f32_to_vec<T>(f));
+          st_vec<T>(dst + 8, f32_to_vec<T>(f + 8));
+        }
       }
       __builtin_amdgcn_wave_barrier();
     }
@@ -187,11 +191,12 @@ __global__ void __launch_bounds__(256) init_conv_mfma_kernel(const InitConvArgs 
     }
   }
 }
-int init_conv_ntiles(int H, int W) { return (H / 16) * (W / 16); }
+// statistics partials per image: the 2-byte engines' MFMA kernel works on 8 x 32 tiles, the fp32 kernel on 16 x 16
+int init_conv_ntiles(int H, int W, bool mfma) { return mfma ? (H / 8) * ((W + 31) / 32) : ((H + 15) / 16) * ((W + 15) / 16); }
 hipError_t launch_init_conv(int dtype, const InitConvArgs& a, hipStream_t s) {
-  if (a.H % 16 || a.W % 16 || a.Cout % 32 || a.c0 + a.c1 > 8) return hipErrorInvalidValue;
-  if (a.wp && dtype != 0 && a.W % 32) return hipErrorInvalidValue;
-  dim3 grid((a.H / 16) * (a.W / 16), a.B);  // 256-pixel tiles: 16 x 16 (VALU kernel) or 8 x 32 (MFMA kernel)
+  if (a.H % 8 || a.W % 8 || a.Cout % 32 || a.c0 + a.c1 > 8) return hipErrorInvalidValue;
+  const bool mfma = a.wp && dtype != 0;
+  dim3 grid(init_conv_ntiles(a.H, a.W, mfma), a.B);  // 256-pixel tiles: 16 x 16 (VALU kernel) or 8 x 32 (MFMA kernel)
   switch (dtype) {
     case 0: hipLaunchKernelGGL(init_conv_kernel<float>, grid, dim3(256), 0, s, a); break;
     case 1:
@@ -217,7 +222,7 @@ __global__ void __launch_bounds__(256) final_conv_kernel(const FinalConvArgs a) 
   constexpr int VPP = 32 / VEC;  // vectors per pixel per 32-channel chunk
   __shared__ float patch[32][18][19];
   const int tid = threadIdx.x;
-  const int tiles_x = a.W / 16;
+  const int tiles_x = (a.W + 15) / 16;  // edge tiles may be partly empty
   const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x, b = blockIdx.y;
   const int x0 = tx * 16, y0 = ty * 16;
   const int py = tid >> 4, px = tid & 15;
@@ -258,7 +263,7 @@ __global__ void __launch_bounds__(256) final_conv_kernel(const FinalConvArgs a) 
   }
 #pragma unroll
   for (int o = 0; o < 4; ++o)
-    if (o < a.Cout) a.out[(((size_t)b * a.Cout + o) * a.H + y0 + py) * a.W + x0 + px] = acc[o] + a.bias[o];
+    if (o < a.Cout && y0 + py < a.H && x0 + px < a.W) a.out[(((size_t)b * a.Cout + o) * a.H + y0 + py) * a.W + x0 + px] = acc[o] + a.bias[o];
 }
 // ---------------------------------------------------------------------------------------------
 // final head on MFMA (2-byte T) with the LCM scheduler step fused into the epilogue.
@@ -277,7 +282,7 @@ __global__ void __launch_bounds__(256) final_conv_mfma_kernel(const FinalConvArg
   constexpr int TH = 256 / TW, PH = TH + 2, PWD = TW + 3, PIX = 40;  // pixel pitch 80 B: conflict-free ds_read_b128 (cf. TilePitch)
   __shared__ __align__(16) T patch[(PH * PWD + 1) * PIX];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int tiles_x = a.W / TW;
+  const int tiles_x = (a.W + TW - 1) / TW;  // edge tiles may be partly empty
   const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x, b = blockIdx.y;
   const int x0 = tx * TW, y0 = ty * TH;
   const T* in = reinterpret_cast<const T*>(a.in) + (size_t)b * a.H * a.W * a.C;
@@ -344,6 +349,7 @@ __global__ void __launch_bounds__(256) final_conv_mfma_kernel(const FinalConvArg
   for (int t = 0; t < 2; ++t) {
     const int g = wave * 2 + t;
     const int y = y0 + g * (32 / TW) + r / TW, x = x0 + r % TW;
+    if (y >= a.H || x >= a.W) continue;
 #pragma unroll
     for (int o = 0; o < 4; ++o) {
       if (o >= a.Cout) break;
@@ -366,10 +372,10 @@ __global__ void __launch_bounds__(256) final_conv_mfma_kernel(const FinalConvArg
   }
 }
 hipError_t launch_final_conv(int dtype, const FinalConvArgs& a, hipStream_t s) {
-  if (a.H % 16 || a.W % 16 || a.C % 32 || a.Cout > 4) return hipErrorInvalidValue;
+  if (a.H % 8 || a.W % 8 || a.C % 32 || a.Cout > 4) return hipErrorInvalidValue;
   if (a.fuse_step && (!a.wp || dtype == 0 || !a.sample || !a.prev || (!a.coef.is_last && !a.noise))) return hipErrorInvalidValue;
   if (!a.fuse_step && !a.out) return hipErrorInvalidValue;
-  dim3 grid((a.H / 16) * (a.W / 16), a.B);
+  dim3 grid(((a.H + 15) / 16) * ((a.W + 15) / 16), a.B);
   switch (dtype) {
     case 0: hipLaunchKernelGGL(final_conv_kernel<float>, grid, dim3(256), 0, s, a); break;
     case 1:
@@ -704,8 +710,8 @@ static hipError_t launch_conv_t(const Conv3Args& a, hipStream_t s) {
   const int Ho = MODE == 0 ? a.Hi / 2 : (MODE == 1 ? a.Hi * 2 : a.Hi), Wo = MODE == 0 ? a.Wi / 2 : (MODE == 1 ? a.Wi * 2 : a.Wi);
   if (Ho < 1 || Wo < 1 || a.Cin % 32 || a.Cout % 32 || (MODE == 0 && (a.Hi % 2 || a.Wi % 2))) return hipErrorInvalidValue;
   const int BN = (a.Cout % 128 == 0) ? 128 : ((a.Cout % 64 == 0) ? 64 : 32);
-  if (Ho % 8 || Wo % 8) {  // partly empty edge tiles: stride-2 convs onto maps that are not a multiple of 8 (image sizes % 64 != 0)
-    if constexpr (MODE == 0) {
+  if (Ho % 8 || Wo % 8) {  // partly empty edge tiles: forward convs onto maps that are not a multiple of 8 (image sizes % 64 != 0)
+    if constexpr (MODE == 0 || MODE == 1) {
       if (BN == 128) return launch_conv_cfg<T, MODE, 8, 128, 2, 2, true>(a, s);
       if (BN == 64) return launch_conv_cfg<T, MODE, 8, 64, 2, 2, true>(a, s);
       return launch_conv_cfg<T, MODE, 8, 32, 2, 1, true>(a, s);

@@ -413,9 +413,9 @@ int build_unet(llie_ctx* c) {
       in_ch = out;
     }
   }
-  // three stride-2 levels; the kernels' tiles have ragged edges down to 4-pixel granularity at the lowest level: any multiple
-  // of 32 (the reference accepts any multiple of 8).  Training needs multiples of 64 (checked in the training entry points).
-  if (g.base_channels % 2 || g.image_size % 32 || g.image_size < 64) return LLIE_ERR_SHAPE;
+  // three stride-2 levels, each followed by a x2 upsample that must restore the size: any multiple of 8, like the reference
+  // (edge tiles of the kernels may be partly empty).  Training needs multiples of 64 (checked in the training entry points).
+  if (g.base_channels % 2 || g.image_size % 8 || g.image_size < 64) return LLIE_ERR_SHAPE;
   if (g.in_channels < 2 || g.in_channels > 8 || g.out_channels > 4) return LLIE_ERR_SHAPE;
 
   c->t_w1 = b.reserve((size_t)T * g.base_channels * 4);
@@ -896,7 +896,7 @@ struct Run {
     const float* filmp = p<float>(film);
     const int64_t fstride = uniform_t ? 0 : F;
 
-    Tens h = new_tens(c->channels[0], S, S, init_conv_ntiles(S, S), c->channels_r[0]);
+    Tens h = new_tens(c->channels[0], S, S, init_conv_ntiles(S, S, dt != LLIE_F32), c->channels_r[0]);
     if (!dry) {
       InitConvArgs a{};
       const int half = g.in_channels / 2;

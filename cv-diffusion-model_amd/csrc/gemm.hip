@@ -440,7 +440,7 @@ hipError_t launch_pw_gemm(int dtype, const GemmArgs& a0, hipStream_t s) {
   if (a.nostore && (!a.stats || a.res)) return hipErrorInvalidValue;
   // host-side shape contract of the kernel (checked before any launch: an out-of-contract shape
   // would index out of bounds on the device)
-  if (a.nseg < 1 || a.nseg > 3 || a.N % 32 || a.K % 32 || a.P % 16 || a.P < 16 || a.M % a.P) return hipErrorInvalidValue;
+  if (a.nseg < 1 || a.nseg > 3 || a.N % 32 || a.K % 32 || a.P < 1 || a.M % a.P) return hipErrorInvalidValue;
   int k = 0;
   for (int i = 0; i < a.nseg; ++i) {
     if (a.seg[i].ch % 32 || a.seg[i].ch <= 0 || !a.seg[i].ptr) return hipErrorInvalidValue;

@@ -185,7 +185,7 @@ struct InitConvArgs {
   int B, H, W, Cout;
 };
 hipError_t launch_init_conv(int dtype, const InitConvArgs& a, hipStream_t s);
-int init_conv_ntiles(int H, int W);
+int init_conv_ntiles(int H, int W, bool mfma);  // mfma: the 2-byte engines' kernel (8 x 32 tiles); else 16 x 16
 //   final: NHWC T -> affine + SiLU -> 3x3 conv C->Cout(3) -> fp32 NCHW; the MFMA variant (2-byte T)
 //   can apply LCMScheduler.step to its own output in the epilogue (fuse_step).
 struct StepCoef { float sa, sb, sap, sbp; int is_last; int vpred; int clamp_x0; };

@@ -33,7 +33,7 @@ typedef void* llie_stream; /* hipStream_t */
 enum llie_status {
   LLIE_OK = 0,
   LLIE_ERR_ARG = -1,       /* null pointer / bad enum / bad size */
-  LLIE_ERR_SHAPE = -2,     /* shape not supported by the engine (e.g. image side not a multiple of 32) */
+  LLIE_ERR_SHAPE = -2,     /* shape not supported by the engine (e.g. image side not a multiple of 8, or below 64) */
   LLIE_ERR_CONFIG = -3,    /* topology the reference itself cannot construct (GroupNorm divisibility) */
   LLIE_ERR_KEY = -4,       /* unknown state_dict key or wrong element count */
   LLIE_ERR_NOT_LOADED = -5,/* forward called before every parameter was loaded */
