@@ -247,7 +247,7 @@ __device__ __forceinline__ void dw_body_impl(const DwArgs& a, const int TYL, con
     pool_segments_add<CC, NT>(red, TYL / kPoolSegRows, tid, a.pool_tot + (size_t)b * a.C + chunk_id * CC, kPoolFixScale);
   } else if (a.pool) {
     wg_barrier();
-    const int ntiles = tiles_x * (a.H / kPoolSegRows);
+    const int ntiles = tiles_x * ((a.H + kPoolSegRows - 1) / kPoolSegRows);
     pool_segments_store<CC, NT>(red, TYL / kPoolSegRows, tid, a.pool + (size_t)b * ntiles * a.C + chunk_id * CC, a.C,
                                 ty * (TYL / kPoolSegRows), tiles_x, tx);
   }
@@ -289,7 +289,7 @@ template <typename T>
 static hipError_t launch_dw_t(const DwArgs& a, hipStream_t s) {
   constexpr int CC = 8 * Elem<T>::VEC;
   const bool ragged = a.H % 8 || a.W % 8;  // forward only: partial strips at the right / bottom edge
-  if (a.C % CC || a.H < 1 || a.W < 1 || (ragged && (a.bx || a.pool))) return hipErrorInvalidValue;
+  if (a.C % CC || a.H < 1 || a.W < 1 || (ragged && a.bx)) return hipErrorInvalidValue;
   const int tx = dw_tx(a.W), tyl = dw_pick_tyl(a.B, a.H, a.W, a.C / CC);
   const int tiles = ((a.W + tx - 1) / tx) * ((a.H + tyl - 1) / tyl);
   dim3 grid(tiles, a.C / CC, a.B);

@@ -207,6 +207,18 @@ def test_image_sizes_that_are_not_multiples_of_64(dev, size, batch):
         m.compute_dtype = None
 
 
+@pytest.mark.parametrize("variant,size", [("large", 96), ("base", 72)])
+def test_ragged_sizes_other_variants(dev, variant, size):
+    """The same at other topologies: `large` (wider channels) and the opt-in zero-padded `base` (pool-slab SE path)."""
+    m, sd, spec = model(variant, size, dev)
+    low = torch.rand(2, 3, size, size, generator=torch.Generator().manual_seed(size)) * 2 - 1
+    noise = oracle.draw_noise(2, size, 4, seed=size + 7)
+    ref = oracle.enhance_ref(sd, spec, low, 4, noise)
+    m.compute_dtype = None
+    out = m.enhance(low.to(dev), 4, noise=torch.stack(noise), return_intermediate=True)
+    assert max(max_abs(a.cpu(), b) for a, b in zip(out.intermediate, ref["intermediate"])) < 1e-3
+
+
 def test_unsupported_image_sizes_are_refused(dev):
     for size in (100, 60, 32):
         with pytest.raises(ValueError):
