@@ -108,10 +108,11 @@ def test_host_io_vs_oracle(shape, size):
 
 
 @pytest.mark.gpu
-def test_cli_end_to_end(tmp_path):
+@pytest.mark.parametrize("size", [64])
+def test_cli_end_to_end(tmp_path, size):
     from PIL import Image
     from oracle import hostio_ref
-    spec = oracle.make_spec("small", 64)
+    spec = oracle.make_spec("small", size)
     sd = oracle.synth_state_dict(oracle.param_shapes(spec))
     ckpt = tmp_path / "ckpt.pt"
     torch.save({"epoch": 1, "model_state_dict": dict(sd)}, ckpt)
@@ -123,7 +124,7 @@ def test_cli_end_to_end(tmp_path):
         Image.fromarray(imgs[-1]).save(src / f"dark{i}.png")
     dst = tmp_path / "out"
     r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "inference.py"), "--input", str(src), "--output", str(dst),
-                        "--checkpoint", str(ckpt), "--variant", "small", "--image_size", "64", "--num_steps", "4",
+                        "--checkpoint", str(ckpt), "--variant", "small", "--image_size", str(size), "--num_steps", "4",
                         "--noise_seed", "77"],
                        capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
@@ -134,9 +135,9 @@ def test_cli_end_to_end(tmp_path):
         # scripts/inference.py:99-145) on the same seeded CPU noise.  The fp32 engine is within 1e-3 of the oracle, so
         # the bytes agree except where a value sits on a truncation / rounding boundary (the denormalisation truncates, the
         # resize back to the original size rounds): never more than one LSB.
-        x, orig = hostio_ref.preprocess_ref(imgs[i], 64)
+        x, orig = hostio_ref.preprocess_ref(imgs[i], size)
         g = torch.Generator().manual_seed(77)
-        noise = [torch.randn(1, 3, 64, 64, generator=g) for _ in range(4)]
+        noise = [torch.randn(1, 3, size, size, generator=g) for _ in range(4)]
         ref = oracle.enhance_ref(sd, spec, torch.from_numpy(x), 4, noise)["enhanced"].numpy()
         want = hostio_ref.postprocess_ref(ref, orig)
         d = np.abs(out.astype(np.int64) - want.astype(np.int64))
@@ -144,7 +145,7 @@ def test_cli_end_to_end(tmp_path):
     bare = tmp_path / "bare.pt"
     torch.save(dict(sd), bare)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "benchmark.py"), "--model", str(bare), "--format", "pytorch",
-                        "--image_size", "64", "--batch_size", "2", "--num_runs", "3", "--warmup", "1", "--device", "cuda"],
+                        "--image_size", str(size), "--batch_size", "2", "--num_runs", "3", "--warmup", "1", "--device", "cuda"],
                        capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
     assert re.search(r"Mean latency:\s+[\d.]+ ms", r.stdout) and "images/s" in r.stdout
