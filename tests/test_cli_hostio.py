@@ -108,8 +108,12 @@ def test_host_io_vs_oracle(shape, size):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("size", [64])
-def test_cli_end_to_end(tmp_path, size):
+# 96: `--image_size` off the multiples of 64 (the reference's CLI takes any multiple of 8).  There the host resize's uint8 rounding
+# (parity-unpinned: cv2 is absent) differs from the oracle's restatement in more input pixels, which the network amplifies
+# to two LSB in a handful of output pixels; through the Python API with identical inputs the two agree to one LSB in
+# < 0.01 % of the pixels at either size (tools/gpu_cli_debug.py).
+@pytest.mark.parametrize("size,max_lsb", [(64, 1), (96, 2)])
+def test_cli_end_to_end(tmp_path, size, max_lsb):
     from PIL import Image
     from oracle import hostio_ref
     spec = oracle.make_spec("small", size)
@@ -141,7 +145,7 @@ def test_cli_end_to_end(tmp_path, size):
         ref = oracle.enhance_ref(sd, spec, torch.from_numpy(x), 4, noise)["enhanced"].numpy()
         want = hostio_ref.postprocess_ref(ref, orig)
         d = np.abs(out.astype(np.int64) - want.astype(np.int64))
-        assert d.max() <= 1 and (d > 0).mean() < 0.15, (d.max(), (d > 0).mean())
+        assert d.max() <= max_lsb and (d > 0).mean() < 0.15, (d.max(), (d > 0).mean())
     bare = tmp_path / "bare.pt"
     torch.save(dict(sd), bare)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "benchmark.py"), "--model", str(bare), "--format", "pytorch",
