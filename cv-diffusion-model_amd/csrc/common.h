@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
 #include <type_traits>
 
 #include "kernels.h"
@@ -21,6 +22,19 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kWave = 64;
+
+// Host: raise a kernel's dynamic-LDS limit once per *device* (the attribute lives in the per-device function object, so a
+// process that drives two GPUs -- enhance_sharded, model.to("cuda:1") -- needs it set on both).  `done` is the call
+// site's static bit mask of devices already handled.
+inline hipError_t ensure_max_lds(const void* fn, int bytes, std::atomic<uint64_t>& done) {
+  int dev = 0;
+  if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) return e;
+  const uint64_t bit = 1ull << (dev & 63);
+  if (done.load(std::memory_order_acquire) & bit) return hipSuccess;
+  if (hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes); e != hipSuccess) return e;
+  done.fetch_or(bit, std::memory_order_release);
+  return hipSuccess;
+}
 
 // ---------------------------------------------------------------------------------------------
 // Element traits: VEC = elements per 16-byte lane vector.

@@ -688,12 +688,11 @@ static hipError_t launch_conv_cfg(const Conv3Args& a, hipStream_t s) {
   constexpr size_t tiles = (size_t)(PH * PW + 2 * BN) * PITCH * sizeof(T);
   constexpr size_t ctile = (size_t)(WM * 32) * (BN + 4) * 4 + (size_t)(NT / 64) * 2 * BN * 4;
   constexpr size_t lds = tiles > ctile ? tiles : ctile;
-  static bool attr_done = false;
-  if (!attr_done && lds > 48 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_kernel<T, MODE, TW, BN, WM, WN, RAGGED>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    attr_done = true;
+  static std::atomic<uint64_t> attr_done{0};
+  if (lds > 48 * 1024) {
+    if (hipError_t e = ensure_max_lds(reinterpret_cast<const void*>(&conv3x3_kernel<T, MODE, TW, BN, WM, WN, RAGGED>), (int)lds, attr_done);
+        e != hipSuccess)
+      return e;
   }
   const int Ho = MODE == 0 ? a.Hi / 2 : (MODE == 1 ? a.Hi * 2 : a.Hi), Wo = MODE == 0 ? a.Wi / 2 : (MODE == 1 ? a.Wi * 2 : a.Wi);
   const unsigned grid = (unsigned)(a.B * ((Ho + 7) / 8) * ((Wo + TW - 1) / TW) * (a.Cout / BN));

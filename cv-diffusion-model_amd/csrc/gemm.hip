@@ -364,12 +364,11 @@ static hipError_t launch_cfg(const GemmArgs& a, hipStream_t s) {
   constexpr size_t tiles = (size_t)(BM + BN) * PITCH * sizeof(T);
   constexpr size_t ctile = (size_t)(WM * 32) * (BN + 4) * 4 + (size_t)(NT / 64) * 2 * BN * 4;
   constexpr size_t lds = tiles > ctile ? tiles : ctile;
-  static bool attr_done = false;
-  if (!attr_done && lds > 48 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pw_gemm_kernel<T, BM, BN, WM, WN, BK, false, RAGGED>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    attr_done = true;
+  static std::atomic<uint64_t> attr_done{0};
+  if (lds > 48 * 1024) {
+    if (hipError_t e = ensure_max_lds(reinterpret_cast<const void*>(&pw_gemm_kernel<T, BM, BN, WM, WN, BK, false, RAGGED>), (int)lds, attr_done);
+        e != hipSuccess)
+      return e;
   }
   const unsigned grid = (unsigned)((a.M / a.P) * ((a.P + BM - 1) / BM) * (a.N / BN));  // == (M / BM) * (N / BN) unless RAGGED
   if constexpr (sizeof(T) == 2 && BM == 128) {

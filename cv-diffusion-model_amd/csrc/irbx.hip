@@ -16,7 +16,9 @@
 //                        [pixel][64 channels] and runs the depthwise 3x3 from there, 64 hidden channels at a time;
 //                        the x tile is loaded once per tile (next tile prefetched) and reused by every channel chunk.
 //
-// Both kernels write fixed per-tile partial sums (no atomics), so results stay bitwise independent of the batch.
+// The GroupNorm partial sums are fixed per-tile slab entries; the SE pool sums go into per-image 64-bit fixed-point
+// totals with integer atomics (integer adds commute).  No float atomics, so results stay bitwise independent of the
+// batch and of the schedule.
 #include <string>
 #include <type_traits>
 #include <vector>
@@ -610,13 +612,9 @@ template <typename T, int KS, bool DBUF>
 static hipError_t launch_dw_cfg(const IrbxArgs& a, hipStream_t s) {
   const size_t lds = (size_t)(DBUF ? 2 : 1) * kXNPB * 32 * SHP + (size_t)kXNPB * 32 * (16 * KS + 8) * 2 + (size_t)9 * a.Chid * 2 +
                      (size_t)2 * a.Chid * 4 + (size_t)2 * 16 * KS * 4 + 2 * 256 * 4;
-  static bool attr_done = false;
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&expand_dw_kernel<T, KS, DBUF>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-    if (e != hipSuccess) return e;
-    attr_done = true;
-  }
+  static std::atomic<uint64_t> attr_done{0};
+  if (hipError_t e = ensure_max_lds(reinterpret_cast<const void*>(&expand_dw_kernel<T, KS, DBUF>), 128 * 1024, attr_done); e != hipSuccess)
+    return e;
   const int ntiles = irbx_pool_tiles(a.H, a.W), nchunks = a.Chid / 64;
   // tiles per workgroup: a run along x (neighbouring halo columns hit L1), as long as the launch keeps >= 2048 workgroups
   int tpw = g_irbx_tiles;

@@ -87,13 +87,18 @@ class LCMScheduler:
         # has drained, i.e. every `enhance` call would wait for the previous one and leave the GPU idle while Python
         # prepares the next launch (measured: 0.7 ms of exposed host time per call, 10 % of a B=1 call)
         dev = torch.device(device)
-        key = (tuple(self._timestep_list), dev.type, dev.index)
+        index = dev.index
+        if dev.type == "cuda" and index is None:  # "cuda" means the *current* device, which set_device can change
+            index = torch.cuda.current_device()
+        key = (tuple(self._timestep_list), dev.type, index)
         cached = self._ts_dev.get(key)
         if cached is None:
             if len(self._ts_dev) > 64:
                 self._ts_dev.clear()
             cached = self._ts_dev[key] = ts.to(dev)
-        self.timesteps = cached
+        # a fresh tensor per call like the reference (:163): a caller editing `timesteps` in place must not poison the
+        # cache.  Device-to-device copy, asynchronous, no host sync.
+        self.timesteps = cached.clone()
         self._step_index = 0
         if self.sigmas.device != dev:
             self.sigmas = self.sigmas.to(dev)

@@ -178,17 +178,33 @@ class _NativeModule(nn.Module):
         c.compute_dtype = dtype_code
         return c
 
-    # Ordered Parameter objects (llie_param_info order), cached: walking named_parameters() costs ~1 ms per call on a
-    # 321-tensor model.  nn.Module replaces Parameter objects only through _apply (with the overwrite-on-conversion
-    # future flag), register_parameter or attribute assignment -- the first two invalidate the cache below, the third is
-    # not something the reference's callers do to this model.
+    # Ordered Parameter objects (llie_param_info order).  What is cached is *where* each one lives -- the `_parameters`
+    # dict of its container and the leaf name -- never the Parameter objects: `load_state_dict(assign=True)`, `mod.weight =
+    # nn.Parameter(...)`, `register_parameter` and `_apply` with the overwrite-on-conversion future flag all replace the
+    # objects inside those dicts, and the engine must follow them (weights to repack, gradients to fill).  321 dict
+    # lookups per call instead of a walk over named_parameters() (~1 ms).  The containers themselves are only replaced
+    # by assigning a whole sub-module, which the identity check over the ~90 parent links notices.
     def _plist(self):
-        pl = self.__dict__.get("_plist_cache")
-        if pl is None:
-            sd = dict(self.named_parameters())
-            pl = [sd[k] for k, _ in self._param_list]
-            object.__setattr__(self, "_plist_cache", pl)
-        return pl
+        cache = self.__dict__.get("_plist_cache")
+        if cache is None:
+            links, seen, slots = [], set(), []   # links: (parent, name, child) for every container on a parameter's path
+            for key, _ in self._param_list:
+                mod, parts = self, key.split(".")
+                for part in parts[:-1]:
+                    child = mod._modules[part]
+                    if id(child) not in seen:
+                        seen.add(id(child))
+                        links.append((mod, part, child))
+                    mod = child
+                slots.append((mod, parts[-1]))
+            cache = (links, slots)
+            object.__setattr__(self, "_plist_cache", cache)
+        links, slots = cache
+        for parent, name, child in links:
+            if parent._modules.get(name) is not child:  # a whole sub-module was swapped: re-resolve the paths
+                object.__setattr__(self, "_plist_cache", None)
+                return self._plist()
+        return [mod._parameters[leaf] for mod, leaf in slots]
 
     def _apply(self, fn, *args, **kwargs):
         object.__setattr__(self, "_plist_cache", None)

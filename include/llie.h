@@ -227,7 +227,9 @@ int llie_copy_probe(const void* src, void* dst, int64_t bytes, llie_stream strea
  *   "gemm_bk" [0 = auto], "gemm_bk128" [1024 = largest grid that takes 128-wide K chunks], "dw_swap" [0],
  *   "bwd_async" [1], "wgrad_target" [1024]
  * Diagnostics whose results are WRONG or slow (timing studies only): "skip_small", "gemm_ablate", "dw_ablate",
- * "irbx_ablate", "gemm_stamp", "irbx_stamp". */
+ * "irbx_ablate", "gemm_stamp", "irbx_stamp".
+ * Threading: the knobs are plain process-wide variables read by every forward; call llie_tune only while no other
+ * thread is inside an llie_* compute call (same rule as the handle itself: SURVEY.md 8b, one stream at a time). */
 int llie_tune(const char* knob, int value);
 int llie_debug_irbx_stamps(double* out4); /* diagnostic builds: see irbx.hip (STAMP) */
 int llie_debug_gemm_stamps(double* out3); /* diagnostic builds: see gemm.hip (STAMP) */

@@ -111,7 +111,7 @@ def test_host_io_vs_oracle(shape, size):
 # 96: `--image_size` off the multiples of 64 (the reference's CLI takes any multiple of 8).  There the host resize's uint8 rounding
 # (parity-unpinned: cv2 is absent) differs from the oracle's restatement in more input pixels, which the network amplifies
 # to two LSB in a handful of output pixels; through the Python API with identical inputs the two agree to one LSB in
-# < 0.01 % of the pixels at either size (tools/gpu_cli_debug.py).
+# < 1 % of the bytes at either size (second assert of the test).
 @pytest.mark.parametrize("size,max_lsb", [(64, 1), (96, 2)])
 def test_cli_end_to_end(tmp_path, size, max_lsb):
     from PIL import Image
@@ -145,7 +145,17 @@ def test_cli_end_to_end(tmp_path, size, max_lsb):
         ref = oracle.enhance_ref(sd, spec, torch.from_numpy(x), 4, noise)["enhanced"].numpy()
         want = hostio_ref.postprocess_ref(ref, orig)
         d = np.abs(out.astype(np.int64) - want.astype(np.int64))
-        assert d.max() <= max_lsb and (d > 0).mean() < 0.15, (d.max(), (d > 0).mean())
+        assert d.max() <= max_lsb and (d > 0).mean() < 0.15, (
+            f"file-to-file vs oracle: max {d.max()} LSB, {(d > 0).mean():.3%} bytes differ -- this bound includes the host "
+            "resize's uint8 rounding, which is parity-unpinned (cv2 absent, the reference holds no resized fixture)")
+        # The network alone, with the resize taken out of the comparison: the oracle is fed the exact tensor the product's
+        # preprocessing produced and its output goes through the product's post-processing.  A regression in the ragged
+        # edge-tile kernels at 96 x 96 cannot hide inside the looser whole-file bound above.
+        xp, origp = M.preprocess_array(imgs[i], size)
+        refp = oracle.enhance_ref(sd, spec, torch.from_numpy(xp), 4, noise)["enhanced"].numpy()
+        wantp = M.postprocess_array(refp, origp)
+        dn = np.abs(out.astype(np.int64) - wantp.astype(np.int64))
+        assert dn.max() <= 1 and (dn > 0).mean() < 0.01, f"network only: max {dn.max()} LSB, {(dn > 0).mean():.3%} bytes differ"
     bare = tmp_path / "bare.pt"
     torch.save(dict(sd), bare)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "benchmark.py"), "--model", str(bare), "--format", "pytorch",
