@@ -56,6 +56,10 @@ struct Param {
   bool has_t = false;
   size_t t_off = 0;
   int64_t goff = 0;
+  // PK_MAT, 2-byte engines: third copy = the matrix times f_scale in MFMA fragment order (pwx.hip: launch_pack_expand)
+  bool has_f = false;
+  size_t f_off = 0;
+  float f_scale = 1.f;
 };
 
 // cin / cout / hid are the PHYSICAL channel counts of the tensors (multiples of 32; hid of 64 for 2-byte types);
@@ -68,6 +72,8 @@ struct IrbW {
   size_t n1g, n1b, n2g, n2b, w_expand, w_dw, se_w1, se_b1, se_w2, se_b2, w_proj;
   int film_off;  // first row of this block inside the concatenated FiLM projection
   size_t w_expand_t, w_proj_t, w_dw_flip;  // training copies: [cin][hid], [hid (+cin)][cout], flipped taps
+  bool has_wf = false;  // expand weights x 6 in MFMA fragment order for the activation-stationary kernel (pwx.hip)
+  size_t w_expand_f = 0;
   int p_first;   // index of this block's first parameter (norm1.weight); the rest follow in registration order
 };
 struct AttnW {
@@ -296,6 +302,13 @@ struct Builder {
     w.n1g = f32(p + ".norm1.weight", cin_r, w.cin); w.n1b = f32(p + ".norm1.bias", cin_r, w.cin);
     w.n2g = f32(p + ".norm2.weight", w.hid_r, w.hid); w.n2b = f32(p + ".norm2.bias", w.hid_r, w.hid);
     w.w_expand = mat(p + ".expand.weight", w.hid_r, cin_r, &w.w_expand_t, w.hid, w.cin);
+    if (c->dt != LLIE_F32 && w.hid == w.hid_r && w.cin == cin_r && w.cin >= 128 && w.cin % 64 == 0 && w.hid % 32 == 0) {
+      // wide blocks of the 2-byte engines: the expand GEMM runs activation-stationary (pwx.hip) from this packed copy
+      w.has_wf = true;
+      w.w_expand_f = reserve((size_t)w.hid * w.cin * es());
+      Param& q = c->params.back();
+      q.has_f = true; q.f_off = w.w_expand_f; q.f_scale = 6.f;  // the 6 of ReLU6 carried as clamp01(z / 6), kernels.h
+    }
     w.w_dw = reserve((size_t)9 * w.hid * 4);
     w.w_dw_flip = reserve((size_t)9 * w.hid * 4);
     { Param& q = add(p + ".depthwise.weight", (int64_t)w.hid_r * 9, PK_DW, w.w_dw); q.O = w.hid_r; q.Op = w.hid; set_shape(q, {w.hid_r, 1, 3, 3});
@@ -686,8 +699,17 @@ struct Run {
       }
       g.w = wptr(w.w_expand); g.out = p(h1.off); g.stats = p<float>(h1.slab);
       g.M = M; g.N = w.hid; g.K = w.cin; g.P = P;
-      timed(LLIE_K_GEMM, ((int64_t)M * (w.cin + w.hid) + (int64_t)w.hid * w.cin) * (int64_t)es(),
-            [&] { return launch_pw_gemm(dt, g, s); });
+      const int64_t kbytes = ((int64_t)M * (w.cin + w.hid) + (int64_t)w.hid * w.cin) * (int64_t)es();
+      if (s6 && w.has_wf && pw_expand_supported(dt, g.seg, g.nseg, M, w.hid, w.cin, P)) {
+        // activation-stationary form: pixels activated once and held in registers, packed weights streamed (pwx.hip)
+        ExpandArgs x{};
+        for (int i = 0; i < g.nseg; ++i) x.seg[i] = g.seg[i];
+        x.nseg = g.nseg; x.wf = wptr(w.w_expand_f); x.out = g.out; x.stats = g.stats;
+        x.M = M; x.N = w.hid; x.K = w.cin; x.P = P;
+        timed(LLIE_K_GEMM, kbytes, [&] { return launch_pw_expand(dt, x, s); });
+      } else {
+        timed(LLIE_K_GEMM, kbytes, [&] { return launch_pw_gemm(dt, g, s); });
+      }
     }
     // norm2 + FiLM folded into one affine
     size_t as2, ab2;
@@ -1636,6 +1658,7 @@ int llie_load_param(llie_ctx* c, const char* key, const float* src, int64_t nume
       e = launch_cvt_rows(p.as_t ? c->dt : 0, src, dst, p.rows, p.cols, p.ld, p.col0, s);
       // transposed copies feed the backward pass, which the padded (unpinned) variants do not have
       if (e == hipSuccess && p.has_t && !c->padded) e = launch_cvt_rows_t(c->dt, src, c->blob + p.t_off, p.rows, p.cols, s);
+      if (e == hipSuccess && p.has_f) e = launch_pack_expand(c->dt, src, c->blob + p.f_off, p.rows, p.cols, p.f_scale, s);
       break;
     case PK_CONV3:
       e = launch_repack_conv3x3(c->dt, src, dst, p.O, p.I, s, p.Op, p.Ip);
@@ -1679,6 +1702,7 @@ static int load_all_impl(llie_ctx* c, const float* const* srcs, int n, llie_stre
       e.src = srcs[i]; e.numel = p.numel; e.dst = (long long)p.off; e.dst_t = p.has_t ? (long long)p.t_off : -1;
       e.as_t = p.as_t ? 1 : 0; e.rows = p.rows; e.cols = p.cols; e.ld = p.ld; e.col0 = p.col0; e.O = p.O; e.I = p.I;
       e.Op = p.Op > 0 ? p.Op : p.O; e.Ip = p.Ip > 0 ? p.Ip : p.I;
+      e.dst_f = p.has_f ? (long long)p.f_off : -1; e.fscale = p.f_scale;
       if (c->padded && p.kind != PK_DW) e.dst_t = -1;  // no backward pass for the padded variants (see llie_load_param)
       switch (p.kind) {
         case PK_F32: e.kind = 0; break;
@@ -2108,6 +2132,25 @@ int llie_pw_gemm(int dtype, const llie_gemm_seg* segs, int nseg, const void* w, 
   return LLIE_OK;
 }
 
+int llie_pw_expand(int dtype, const llie_gemm_seg* segs, int nseg, const float* w32, void* wpack, void* out, float* stats,
+                   int M, int N, int P, llie_stream stream) {
+  if (!segs || nseg < 1 || nseg > 3 || !wpack || !out || !stats || dtype < 1 || dtype > 2) return LLIE_ERR_ARG;
+  ExpandArgs x{};
+  x.nseg = nseg;
+  for (int i = 0; i < nseg; ++i) {
+    x.seg[i] = GemmSeg{segs[i].ptr, segs[i].channels, segs[i].scale, segs[i].bias, segs[i].affine_ld, segs[i].act};
+    x.K += segs[i].channels;
+  }
+  x.wf = wpack; x.out = out; x.stats = stats; x.M = M; x.N = N; x.P = P;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  hipError_t e = !pw_expand_supported(dtype, x.seg, nseg, M, N, x.K, P) ? hipErrorInvalidValue
+                 : (w32 ? launch_pack_expand(dtype, w32, wpack, N, x.K, 6.f, s) : hipSuccess);
+  if (e == hipSuccess) e = launch_pw_expand(dtype, x, s);
+  if (e == hipErrorInvalidValue) { set_err("pw_expand: shape outside the kernel contract"); return LLIE_ERR_SHAPE; }
+  if (e != hipSuccess) { set_err("pw_expand: %s", hipGetErrorString(e)); return (int)e; }
+  return LLIE_OK;
+}
+
 int llie_dwconv3x3(int dtype, const void* in, void* out, const float* scale, const float* bias, const float* w9c,
                    float* pool, int B, int H, int W, int C, llie_stream stream) {
   if (!in || !out || !scale || !bias || !w9c || dtype < 0 || dtype > 2) return LLIE_ERR_ARG;
@@ -2157,6 +2200,14 @@ int llie_copy_probe(const void* src, void* dst, int64_t bytes, llie_stream strea
   return LLIE_OK;
 }
 
+int llie_rw_probe(const void* src, void* dst, int64_t units, int reads, int writes, int nontemporal, llie_stream stream) {
+  if (!src || !dst || units <= 0) return LLIE_ERR_ARG;
+  hipError_t e = launch_rw_probe(src, dst, units, reads, writes, nontemporal, reinterpret_cast<hipStream_t>(stream));
+  if (e == hipErrorInvalidValue) return LLIE_ERR_ARG;
+  if (e != hipSuccess) { set_err("rw_probe: %s", hipGetErrorString(e)); return (int)e; }
+  return LLIE_OK;
+}
+
 int llie_dwconv3x3_tiles(int H, int W) { return dwconv_ntiles(H, W); }
 int llie_pw_gemm_tile_rows(int P) { return pw_gemm_tile_rows(P); }
 
@@ -2174,6 +2225,9 @@ int llie_tune(const char* knob, int value) {
   if (!strcmp(knob, "irbx_mask")) { g_irbx_mask = value; return LLIE_OK; }
   if (!strcmp(knob, "irbx_ablate")) { irbx_ablate(value); return LLIE_OK; }
   if (!strcmp(knob, "gemm_stamp")) { pw_gemm_stamp(value); return LLIE_OK; }
+  if (!strcmp(knob, "pwx")) { pw_expand_enable(value); return LLIE_OK; }
+  if (!strcmp(knob, "pwx_ablate")) { pw_expand_debug(value, -1); return LLIE_OK; }
+  if (!strcmp(knob, "pwx_stamp")) { pw_expand_debug(-1, value); return LLIE_OK; }
   if (!strcmp(knob, "gemm_ablate")) { pw_gemm_debug(value); return LLIE_OK; }
   if (!strcmp(knob, "dw_ablate")) { dwconv_debug(value); return LLIE_OK; }
   if (!strcmp(knob, "dw_swap")) { dwconv_swap(value); return LLIE_OK; }
@@ -2189,6 +2243,13 @@ int llie_debug_gemm_stamps(double* out3) {
   if (e == hipSuccess) e = pw_gemm_stamp_fetch(out3);
   return e == hipSuccess ? LLIE_OK : LLIE_ERR_ARG;
 }
+int llie_debug_pwx_stamps(double* out3) {
+  if (!out3) return LLIE_ERR_ARG;
+  hipError_t e = hipDeviceSynchronize();
+  if (e == hipSuccess) e = pw_expand_stamp_fetch(out3);
+  return e == hipSuccess ? LLIE_OK : LLIE_ERR_ARG;
+}
+
 // diagnostic: mean per-wave cycles of the last stamped expand_dw launch (llie_tune("irbx_stamp", 1)); synchronises
 int llie_debug_irbx_stamps(double* out4) {
   if (!out4) return LLIE_ERR_ARG;

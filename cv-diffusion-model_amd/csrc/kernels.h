@@ -62,6 +62,30 @@ void pw_gemm_force_bk(int bk);  // tuning knob (0 = automatic)
 void pw_gemm_bk128(int max_grid);  // 128-wide K chunks for launches of up to this many workgroups (0 = never)
 void pw_gemm_debug(int v);      // timing ablations; results are wrong when non-zero
 
+// Expanding pointwise GEMM in activation-stationary form (pwx.hip; 2-byte T, every segment ACT_RELU6_S6):
+//   out[M][N] = sum_seg clamp01(A_seg * as + ab) . Wf^T,  Wf = the [N][K] weights times 6, pre-packed in MFMA fragment order
+//   (launch_pack_expand), plus the statistics slab of `out` at 128-row granularity (== pw_gemm_tile_rows for P % 128 == 0).
+struct ExpandArgs {
+  GemmSeg seg[3];
+  int nseg;
+  const void* wf;
+  void* out;
+  float* stats;
+  int M, N, K, P;
+  int nsplit;  // set by the launcher
+  unsigned long long* stamps;  // diagnostic builds only (pw_expand_debug)
+};
+__host__ __device__ inline long long pw_expand_pack_index(int n, int k, int K) {
+  const int lane = (n & 31) + 32 * ((k >> 3) & 1);
+  return ((((long long)(n >> 5) * (K >> 4) + (k >> 4)) * 64 + lane) << 3) + (k & 7);
+}
+bool pw_expand_supported(int dtype, const GemmSeg* seg, int nseg, int M, int N, int K, int P);
+hipError_t launch_pw_expand(int dtype, const ExpandArgs& a, hipStream_t s);
+hipError_t launch_pack_expand(int dtype, const float* src, void* dst, int N, int K, float scale, hipStream_t s);
+void pw_expand_enable(int v);  // knob "pwx" (1 = use where supported)
+void pw_expand_debug(int ablate, int stamp);  // timing studies (results wrong when ablate != 0); -1 = leave unchanged
+hipError_t pw_expand_stamp_fetch(double* out3);
+
 // GroupNorm statistics -> per-(image, channel) affine tables.
 //   mean/var over groups of cg = C/32 channels x P pixels from up to two slabs (virtual concat),
 //   as[b][c] = rstd*gamma[c]*(1+fs),  ab[b][c] = (beta[c] - mean*rstd*gamma[c])*(1+fs) + fh
@@ -262,6 +286,8 @@ struct LoadDesc {
   int as_t;            // matrix: destination in the compute dtype (1) or fp32 (0)
   int rows, cols, ld, col0, O, I, Op, Ip;  // Op / Ip: padded destination dims of the 3x3 / depthwise layouts
   long long numel, dst, dst_t;
+  long long dst_f;     // matrix: third copy, times fscale, in MFMA fragment order (pw_expand_pack_index); -1 = none
+  float fscale;
 };
 // state (optional, device): [0] = content hash of the last load, [1] = 1 when the parameters changed (set by launch_params_hash);
 // with a state the kernel is a no-op when [1] == 0
@@ -279,6 +305,7 @@ hipError_t launch_lcm_step(const float* eps, const float* x, const float* noise,
 hipError_t launch_add_noise(const float* x0, const float* noise, const int64_t* t, const float* acp, float* out,
                             int B, int64_t per, int velocity, int table_len, hipStream_t s);
 hipError_t launch_copy_probe(const void* src, void* dst, int64_t bytes, hipStream_t s);
+hipError_t launch_rw_probe(const void* src, void* dst, int64_t units, int r, int w, int nt, hipStream_t s);
 
 
 // =============================================================================================

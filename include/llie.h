@@ -213,26 +213,39 @@ typedef struct llie_gemm_seg {
 int llie_pw_gemm(int dtype, const llie_gemm_seg* segs, int nseg, const void* w, const float* bias, const void* residual,
                  void* out, float* stats, int M, int N, int P, llie_stream stream);
 int llie_pw_gemm_tile_rows(int P);
+/* llie_pw_expand: the expanding 1x1 conv of the wide InvertedResidualBlocks (efficient_unet.py:174 with norm1 + ReLU6
+ *   :207-208 in the prologue, norm2's statistics :212 in the epilogue) in its activation-stationary form (2-byte dtypes;
+ *   K in {128, 192, 256, 384, 512}, P a multiple of 128, every segment with act 3 = clamp01 tables already divided by 6):
+ *   out[M][N] = sum_seg clamp01(A_seg * scale + bias) . (6 W)^T.  w32 = fp32 [N][K] as saved by the reference; wpack = N*K
+ *   elements of T that receive the fragment-ordered copy the engine keeps per layer (w32 == NULL: wpack already holds it,
+ *   from an earlier call with the same weights -- the GEMM alone).  stats: as llie_pw_gemm. */
+int llie_pw_expand(int dtype, const llie_gemm_seg* segs, int nseg, const float* w32, void* wpack, void* out, float* stats,
+                   int M, int N, int P, llie_stream stream);
 int llie_dwconv3x3(int dtype, const void* in, void* out, const float* scale, const float* bias, const float* w9c,
                    float* pool, int B, int H, int W, int C, llie_stream stream);
 int llie_dwconv3x3_tiles(int H, int W);
 /* dst[0:bytes] = src[0:bytes] with 16-byte lane accesses: the on-box HBM copy-bandwidth probe behind bench.py's
  * `peak_measured` ("a copy-kernel bandwidth probe"; 2 x bytes move per call). */
 int llie_copy_probe(const void* src, void* dst, int64_t bytes, llie_stream stream);
+/* Streaming probe with a chosen read : write mix: `units` steps, each reading `reads` and writing `writes` 16 KB blocks
+ * ((reads, writes) in {(1,0),(0,1),(1,1),(1,2),(1,4),(2,1),(4,1)}; src holds units*reads, dst units*writes blocks).
+ * The ceiling the write-dominated 4x expansions (efficient_unet.py:174) are compared with. */
+int llie_rw_probe(const void* src, void* dst, int64_t units, int reads, int writes, int nontemporal, llie_stream stream);
 /* Engine knobs (process-wide; every call starts a new epoch of the hipGraph cache).  Production defaults in brackets.
  *   "enhance_split"  [2]    concurrent batch branches of the captured enhance graph (1 = one chain; env LLIE_ENHANCE_SPLIT)
  *   "irbx"           [1]    recompute form of the inverted-residual front half (0 = expand GEMM + depthwise kernel)
  *   "irbx_dbuf" [0], "irbx_tiles" [4], "irbx_mask" [7]   variants of the recompute kernels (A/B runs)
  *   "ztot"           [1]    SE pool as fixed-point totals + fused gate kernel (0 = slab + pool / fc1 / fc2 launches)
  *   "gemm_bk" [0 = auto], "gemm_bk128" [1024 = largest grid that takes 128-wide K chunks], "dw_swap" [0],
- *   "bwd_async" [1], "wgrad_target" [1024]
+ *   "bwd_async" [1], "wgrad_target" [1024], "pwx" [1] (activation-stationary expand GEMM, pwx.hip; 0 = tile kernel)
  * Diagnostics whose results are WRONG or slow (timing studies only): "skip_small", "gemm_ablate", "dw_ablate",
- * "irbx_ablate", "gemm_stamp", "irbx_stamp".
+ * "irbx_ablate", "gemm_stamp", "irbx_stamp", "pwx_ablate", "pwx_stamp".
  * Threading: the knobs are plain process-wide variables read by every forward; call llie_tune only while no other
  * thread is inside an llie_* compute call (same rule as the handle itself: SURVEY.md 8b, one stream at a time). */
 int llie_tune(const char* knob, int value);
 int llie_debug_irbx_stamps(double* out4); /* diagnostic builds: see irbx.hip (STAMP) */
 int llie_debug_gemm_stamps(double* out3); /* diagnostic builds: see gemm.hip (STAMP) */
+int llie_debug_pwx_stamps(double* out3);  /* diagnostic builds: see pwx.hip (STAMP): {A phase, channel loop} cycles per wave, waves */
 
 /* Per-kernel-class timing with HIP events recorded on the launch stream (what bench.py's `roofline`
  * object is computed from).  llie_profile_begin arms recording for the classes in `class_mask`;

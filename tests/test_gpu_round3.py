@@ -1,0 +1,152 @@
+"""GPU parity tests added in round 3 (through the C ABI).
+
+  * the activation-stationary expand GEMM (pwx.hip, llie_pw_expand) against a plain PyTorch fp32 restatement of the same
+    operator (efficient_unet.py:207-208 norm1 + ReLU6 prologue, :174 expand, the statistics norm2 :212 needs), against the
+    tile kernel it replaces (llie_pw_gemm), bitwise batch invariance, and through the whole network (knob "pwx")
+"""
+import importlib
+import math
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from conftest import synth_input
+
+pytestmark = pytest.mark.gpu
+M = importlib.import_module("cv-diffusion-model_amd")
+N = importlib.import_module("cv-diffusion-model_amd._native")
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def _expand_case(dev, tdt, segs, nout, P, B, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    K = sum(segs)
+    xs = [(torch.randn(B * P, c, generator=g) * 1.5).to(tdt) for c in segs]
+    w32 = torch.randn(nout, K, generator=g) / math.sqrt(K)
+    # tables as gn_finalize emits them for ACT_RELU6_S6: scale / 6 and shift / 6 per (image, channel)
+    sc = (torch.rand(B, K, generator=g) + 0.5) / 6
+    bi = (torch.randn(B, K, generator=g) * 0.5 + 0.4) / 6
+    return xs, w32, sc, bi
+
+
+def _run_expand(dev, dtype, tdt, xs, w32, sc, bi, nout, P, B):
+    L = N.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    K = w32.shape[1]
+    xd = [x.to(dev) for x in xs]
+    scd, bid, wd = sc.to(dev), bi.to(dev), w32.to(dev)
+    out = torch.full((B * P, nout), float("nan"), dtype=tdt, device=dev)
+    wpack = torch.empty(nout * K, dtype=tdt, device=dev)
+    stats = torch.full((B, P // 128, 2, nout), float("nan"), device=dev)
+    arr = (N.GemmSeg * len(xs))()
+    off = 0
+    for i, x in enumerate(xd):
+        arr[i] = N.GemmSeg(x.data_ptr(), x.shape[1], scd.data_ptr() + off * 4, bid.data_ptr() + off * 4, K, 3)
+        off += x.shape[1]
+    N.check(L.llie_pw_expand(dtype, arr, len(xs), wd.data_ptr(), wpack.data_ptr(), out.data_ptr(), stats.data_ptr(),
+                             B * P, nout, P, st), "pw_expand")
+    # the tile kernel on the same operands (weights rounded to T, x 6 in its epilogue)
+    out2 = torch.empty_like(out)
+    stats2 = torch.empty_like(stats)
+    wt = wd.to(tdt)
+    N.check(L.llie_pw_gemm(dtype, arr, len(xs), wt.data_ptr(), None, None, out2.data_ptr(), stats2.data_ptr(), B * P, nout, P, st), "pw_gemm")
+    torch.cuda.synchronize()
+    return out.cpu(), stats.cpu(), out2.cpu(), stats2.cpu()
+
+
+@pytest.mark.parametrize("dtype,tdt,ulp", [(1, torch.float16, 2.0 ** -10), (2, torch.bfloat16, 2.0 ** -7)])
+@pytest.mark.parametrize("segs,nout,P,B", [([128], 512, 256, 3), ([128, 64], 768, 128, 2), ([256], 1024, 1024, 2),
+                                           ([256, 128], 1536, 256, 1), ([256, 256], 2048, 128, 2), ([128], 512, 4096, 2)])
+def test_pw_expand_vs_torch_and_tile_kernel(dev, dtype, tdt, ulp, segs, nout, P, B):
+    xs, w32, sc, bi = _expand_case(dev, tdt, segs, nout, P, B, seed=len(segs) * 1000 + nout)
+    out, stats, out2, stats2 = _run_expand(dev, dtype, tdt, xs, w32, sc, bi, nout, P, B)
+    assert torch.isfinite(out.float()).all() and torch.isfinite(stats).all()
+    # plain PyTorch restatement (fp32 on the operands as the kernel sees them: activation rounded once to T, weights = T(6 W))
+    x = torch.cat([v.float() for v in xs], 1).view(B, P, -1)
+    a = (x.double() * sc[:, None, :].double() + bi[:, None, :].double()).clamp(0, 1).to(tdt).double()
+    w6 = (w32 * 6).to(tdt).double()
+    ref = (a @ w6.t()).view(B * P, nout)
+    err = (out.double() - ref).abs()
+    # one rounding to T of an fp32-accumulated sum, plus the rare activation whose own rounding to T falls the other way
+    # (fp32 FMA on the device, float64 here: one unit in the last place of a' <= 1 times one weight, |6 W| < 2.5)
+    tol = ulp * ref.abs() + ulp * 2.5
+    assert (err <= tol).all(), (err / tol).max().item()
+    assert (err.norm() / ref.norm()).item() < ulp / 2
+    # statistics: exactly the sums of the values that were stored (fp32 summation order aside)
+    o = out.double().view(B, P // 128, 128, nout)
+    s_ref = torch.stack([o.sum(2), (o * o).sum(2)], 2)
+    assert torch.allclose(stats.double(), s_ref, rtol=2e-6, atol=1e-3), (stats.double() - s_ref).abs().max().item()
+    # the kernel it replaces computes T(6 * (a . T(W))): same values up to the weights' rounding
+    rel = (out.double() - out2.double()).norm() / out2.double().norm()
+    assert rel < 4 * ulp, rel.item()
+    assert torch.allclose(stats[:, :, 0].double(), stats2[:, :, 0].double(), rtol=0.02, atol=0.3 * math.sqrt(128) * max(1.0, float(out2.float().abs().max())) * ulp * 8)
+
+
+def test_pw_expand_is_bitwise_batch_invariant(dev):
+    tdt, P, nout, segs = torch.float16, 1024, 1024, [256]
+    xs, w32, sc, bi = _expand_case(dev, tdt, segs, nout, P, 4, seed=5)
+    out4, st4, _, _ = _run_expand(dev, 1, tdt, xs, w32, sc, bi, nout, P, 4)
+    for b in (0, 3):  # a single image alone (different grid, different nsplit) gives the same bits
+        out1, st1, _, _ = _run_expand(dev, 1, tdt, [x[b * P:(b + 1) * P] for x in xs], w32, sc[b:b + 1], bi[b:b + 1], nout, P, 1)
+        assert torch.equal(out1, out4[b * P:(b + 1) * P]) and torch.equal(st1[0], st4[b])
+    again, st_again, _, _ = _run_expand(dev, 1, tdt, xs, w32, sc, bi, nout, P, 4)
+    assert torch.equal(again, out4) and torch.equal(st_again, st4)
+
+
+def test_pw_expand_refuses_shapes_outside_its_contract(dev):
+    L = N.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    x = torch.zeros(256, 96, dtype=torch.float16, device=dev)
+    t = torch.zeros(1, 96, device=dev)
+    w = torch.zeros(384, 96, device=dev)
+    buf = torch.zeros(384 * 256, dtype=torch.float16, device=dev)
+    stats = torch.zeros(2 * 2 * 384, device=dev)
+    arr = (N.GemmSeg * 1)(N.GemmSeg(x.data_ptr(), 96, t.data_ptr(), t.data_ptr(), 96, 3))
+    assert L.llie_pw_expand(1, arr, 1, w.data_ptr(), buf.data_ptr(), buf.data_ptr(), stats.data_ptr(), 256, 384, 128, st) == -2  # K = 96
+    x2 = torch.zeros(192, 128, dtype=torch.float16, device=dev)
+    arr = (N.GemmSeg * 1)(N.GemmSeg(x2.data_ptr(), 128, t.data_ptr(), t.data_ptr(), 128, 3))
+    assert L.llie_pw_expand(1, arr, 1, w.data_ptr(), buf.data_ptr(), buf.data_ptr(), stats.data_ptr(), 192, 512, 96, st) == -2  # P % 128
+    arr = (N.GemmSeg * 1)(N.GemmSeg(x2.data_ptr(), 128, t.data_ptr(), t.data_ptr(), 128, 1))
+    assert L.llie_pw_expand(1, arr, 1, w.data_ptr(), buf.data_ptr(), buf.data_ptr(), stats.data_ptr(), 128, 512, 128, st) == -2  # act != 3
+    assert L.llie_pw_expand(0, arr, 1, w.data_ptr(), buf.data_ptr(), buf.data_ptr(), stats.data_ptr(), 128, 512, 128, st) == -1   # fp32
+
+
+def _psnr01(a, b):
+    a = (a.double().clamp(-1, 1) + 1) / 2
+    b = (b.double().clamp(-1, 1) + 1) / 2
+    mse = ((a - b) ** 2).mean().item()
+    return 99.0 if mse == 0 else 10 * math.log10(1.0 / mse)
+
+
+@pytest.mark.parametrize("cd,min_psnr", [("fp16", 50.0), ("bf16", 32.0)])
+def test_whole_network_with_and_without_activation_stationary_expand(dev, cd, min_psnr):
+    """small@128 (wide blocks at 32 x 32 and 16 x 16 pixels take the new kernel; the 16 x 16 level has P = 256): against
+    the fp32 CPU oracle by PSNR with the knob on and off, and the two engines against each other."""
+    L = N.lib()
+    spec = oracle.make_spec("small", 128)
+    sd = oracle.synth_state_dict(oracle.param_shapes(spec))
+    m = M.LowLightDiffusion(unet_variant="small", image_size=128, num_inference_steps=4, compute_dtype=cd)
+    m.load_state_dict(sd)
+    m = m.to(dev).eval()
+    low = synth_input("r3:low128", (3, 3, 128, 128), -1.0, -0.4)
+    noise = oracle.draw_noise(3, 128, 4, seed=21)
+    ref = oracle.enhance_ref(sd, spec, low, 4, noise)["enhanced"]
+    outs = {}
+    try:
+        for knob in (1, 0):
+            N.check(L.llie_tune(b"pwx", knob))
+            outs[knob] = m.enhance(low.to(dev), 4, noise=torch.stack(noise)).cpu()
+            assert _psnr01(outs[knob], ref) >= min_psnr, (knob, _psnr01(outs[knob], ref))
+    finally:
+        L.llie_tune(b"pwx", 1)
+    assert _psnr01(outs[1], outs[0]) >= min_psnr
+    # sub-batches stay bitwise identical with the new kernel in the path
+    one = m.enhance(low[1:2].to(dev), 4, noise=torch.stack(noise)[:, 1:2]).cpu()
+    assert torch.equal(one[0], outs[1][1])

@@ -61,6 +61,36 @@ def gemm(kind, M, segs, Nout, P, dtype=1, B=32, act=1):
     return us, nbytes / us / 1e3, flops / us / 1e6
 
 
+def expand(M, segs, Nout, P, dtype=1, B=32):
+    """The activation-stationary expand GEMM (llie_pw_expand) and the tile kernel on the same operands."""
+    tdt = torch.float16 if dtype == 1 else torch.bfloat16
+    K = sum(segs)
+    a = [torch.randn(M, c, device=dev, dtype=tdt) for c in segs]
+    w32 = torch.randn(Nout, K, device=dev) * 0.05
+    wt = w32.to(tdt)
+    wpack = torch.empty(Nout * K, device=dev, dtype=tdt)
+    out = torch.empty(M, Nout, device=dev, dtype=tdt)
+    sc = (torch.rand(B, K, device=dev) + 0.5) / 6
+    bi = torch.randn(B, K, device=dev) * 0.1
+    stats = torch.empty(B * (P // 128) * 2 * Nout, device=dev)
+    arr = (N.GemmSeg * len(segs))()
+    off = 0
+    for i, c in enumerate(segs):
+        arr[i] = N.GemmSeg(a[i].data_ptr(), c, sc.data_ptr() + off * 4, bi.data_ptr() + off * 4, K, 3)
+        off += c
+    N.check(L.llie_pw_expand(dtype, arr, len(segs), w32.data_ptr(), wpack.data_ptr(), out.data_ptr(), stats.data_ptr(), M, Nout, P, st()))
+    L.llie_tune(b"pwx", 1)
+
+    def run_new():  # the pack is a load-time cost in the engine: time the GEMM alone through the engine's launcher
+        N.check(L.llie_pw_expand(dtype, arr, len(segs), None, wpack.data_ptr(), out.data_ptr(), stats.data_ptr(), M, Nout, P, st()))
+
+    def run_old():
+        N.check(L.llie_pw_gemm(dtype, arr, len(segs), wt.data_ptr(), None, None, out.data_ptr(), stats.data_ptr(), M, Nout, P, st()))
+    nbytes = (M * K + M * Nout) * 2
+    flops = 2.0 * M * K * Nout
+    return time_it(run_new), time_it(run_old), nbytes, flops
+
+
 def dw(B, H, C, dtype=1):
     tdt = torch.float16 if dtype == 1 else torch.float32
     x = torch.randn(B, H, H, C, device=dev, dtype=tdt)
@@ -102,6 +132,32 @@ if __name__ == "__main__":
                 row.append(f"{us:8.1f}us {tf:4.0f}TF {gbs:5.0f}GB/s")
             print(f"{name:28s} " + " ".join(f"{r:>26s}" for r in row), flush=True)
         print("sum(us):", {k: round(v, 1) for k, v in tot.items()})
+    if "expand" in sys.argv[1:]:  # activation-stationary expand GEMM vs the tile kernel; usage: gpu_tune.py expand [B]
+        i = sys.argv.index("expand")
+        Bx = int(sys.argv[i + 1]) if len(sys.argv) > i + 1 else 32
+        tot_n = tot_o = 0.0
+        for rep in range(2):
+            for name, kind, P, segs, n in SHAPES + [("enc3.0 K1 128->512", "k1", 1024, [128], 512)]:
+                if kind != "k1" or sum(segs) < 128:
+                    continue
+                un, uo, nb, fl = expand(Bx * P, segs, n, P, B=Bx)
+                tot_n += un; tot_o += uo
+                print(f"B={Bx} {name:24s} pwx {un:7.1f} us {nb / un / 1e3:5.0f} GB/s {fl / un / 1e6:4.0f} TF | tile kernel {uo:7.1f} us {nb / uo / 1e3:5.0f} GB/s {fl / uo / 1e6:4.0f} TF", flush=True)
+        print(f"sum: pwx {tot_n / 2:.1f} us, tile kernel {tot_o / 2:.1f} us")
+    if "expand_diag" in sys.argv[1:]:  # where the activation-stationary kernel spends its time (two representative shapes)
+        out = (C.c_double * 3)()
+        for name, P, segs, n in [("dec2.0 K1 192->768", 16384, [128, 64], 768), ("dec1.0 K1 384->1536", 4096, [256, 128], 1536)]:
+            row = []
+            for abl in (0, 1, 2, 0, 1, 2):
+                L.llie_tune(b"pwx_ablate", abl)
+                un, _, nb, fl = expand(B * P, segs, n, P)
+                row.append(f"abl{abl}: {un:7.1f}us")
+            L.llie_tune(b"pwx_ablate", 0)
+            L.llie_tune(b"pwx_stamp", 1)
+            un, _, nb, fl = expand(B * P, segs, n, P)
+            N.check(L.llie_debug_pwx_stamps(out))
+            L.llie_tune(b"pwx_stamp", 0)
+            print(f"{name:22s} " + " | ".join(row) + f" | stamped {un:7.1f}us: A phase {out[0]:8.0f} cyc, channel loop {out[1]:8.0f} cyc per wave ({out[2]:.0f} waves)", flush=True)
     if "gemm_stamp" in sys.argv[1:]:
         out = (C.c_double * 3)()
         for name, kind, P, segs, n in SHAPES:
