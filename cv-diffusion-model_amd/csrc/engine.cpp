@@ -2228,6 +2228,7 @@ int llie_tune(const char* knob, int value) {
   if (!strcmp(knob, "pwx")) { pw_expand_enable(value); return LLIE_OK; }
   if (!strcmp(knob, "pwx_ablate")) { pw_expand_debug(value, -1); return LLIE_OK; }
   if (!strcmp(knob, "pwx_stamp")) { pw_expand_debug(-1, value); return LLIE_OK; }
+  if (!strcmp(knob, "pwx_nbw")) { pw_expand_debug(-1, -1, value); return LLIE_OK; }
   if (!strcmp(knob, "gemm_ablate")) { pw_gemm_debug(value); return LLIE_OK; }
   if (!strcmp(knob, "dw_ablate")) { dwconv_debug(value); return LLIE_OK; }
   if (!strcmp(knob, "dw_swap")) { dwconv_swap(value); return LLIE_OK; }
@@ -2243,10 +2244,10 @@ int llie_debug_gemm_stamps(double* out3) {
   if (e == hipSuccess) e = pw_gemm_stamp_fetch(out3);
   return e == hipSuccess ? LLIE_OK : LLIE_ERR_ARG;
 }
-int llie_debug_pwx_stamps(double* out3) {
-  if (!out3) return LLIE_ERR_ARG;
+int llie_debug_pwx_stamps(double* out4) {
+  if (!out4) return LLIE_ERR_ARG;
   hipError_t e = hipDeviceSynchronize();
-  if (e == hipSuccess) e = pw_expand_stamp_fetch(out3);
+  if (e == hipSuccess) e = pw_expand_stamp_fetch(out4);
   return e == hipSuccess ? LLIE_OK : LLIE_ERR_ARG;
 }
 

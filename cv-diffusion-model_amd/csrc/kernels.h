@@ -83,8 +83,8 @@ bool pw_expand_supported(int dtype, const GemmSeg* seg, int nseg, int M, int N, 
 hipError_t launch_pw_expand(int dtype, const ExpandArgs& a, hipStream_t s);
 hipError_t launch_pack_expand(int dtype, const float* src, void* dst, int N, int K, float scale, hipStream_t s);
 void pw_expand_enable(int v);  // knob "pwx" (1 = use where supported)
-void pw_expand_debug(int ablate, int stamp);  // timing studies (results wrong when ablate != 0); -1 = leave unchanged
-hipError_t pw_expand_stamp_fetch(double* out3);
+void pw_expand_debug(int ablate, int stamp, int nbw = -1);  // timing studies (results wrong when 0 < ablate < 6); -1 = leave unchanged
+hipError_t pw_expand_stamp_fetch(double* out4);
 
 // GroupNorm statistics -> per-(image, channel) affine tables.
 //   mean/var over groups of cg = C/32 channels x P pixels from up to two slabs (virtual concat),

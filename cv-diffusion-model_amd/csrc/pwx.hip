@@ -18,8 +18,10 @@
 //   * the epilogue never touches LDS with the tile: accumulators (lane = channel, registers = pixels) are rounded to T,
 //     the GroupNorm partial sums come from v_dot2 on the packed words (a lane's 16 pixels, one half-swap, one LDS word
 //     per wave and channel), the tile is transposed ON THE MATRIX PIPE (two MFMAs against a 0/1 selection matrix: exact)
-//     into lane = pixel, registers = channels, and leaves as 16-byte stores after v_permlane32_swap -- a steady
-//     trickle of stores under the next block's MFMAs instead of a burst per tile.
+//     into lane = pixel, registers = channels; after v_permlane32_swap a lane owns 16-byte runs of one pixel's channels,
+//     which go through a wave-private 4.5 KB LDS tile (no barrier) and leave, every second block, as four stores of
+//     8 rows x 128 bytes -- whole cache lines (32-byte pieces straight from registers cost 30 % of the launch:
+//     profiles/r03/pwx_store_shape.txt), a steady trickle under the next block's MFMAs instead of a burst per tile.
 //
 // Statistics are fixed per-(128-pixel tile, channel) slab entries summed in a fixed order: bitwise independent of the batch.
 #include <string>
@@ -57,22 +59,29 @@ template <typename T> __device__ __forceinline__ f32x16 mfma_u(const u32x4& a, c
 template <typename T> constexpr uint32_t one_bits() { return std::is_same<T, half_t>::value ? 0x3C00u : 0x3F80u; }
 
 constexpr int kStagePitch = 144;  // bytes per staged 64-channel row: 128 + one 16-byte pad (conflict-free ds_read_b128)
+constexpr bool pwx_has_tile(int KS, int NBW, int ABL) { return ABL == 0 || NBW * KS * 1024 < 4 * 32 * kStagePitch; }
+constexpr int pwx_lds_bytes(int KS, int NBW, int ABL) {
+  return 2 * NBW * KS * 1024 + 2 * 4 * NBW * 64 * 4 + (pwx_has_tile(KS, NBW, ABL) ? 4 * 32 * kStagePitch : 0);
+}
 
 }  // namespace
 
 // KS = K / 16 MFMA steps; NBW = 32-channel blocks per LDS buffer.
+// ABL 6 = stores straight from registers (32 rows x 32 bytes per instruction; correct results).
 // Diagnostic instantiations (llie_tune "pwx_ablate" / "pwx_stamp", timing studies only): ABL 1 = every store instruction
-// writes 1 KB of contiguous memory (wrong layout, same bytes), 2 = no output stores; STAMP = s_memtime per wave after the
-// A phase and at the end.  Template parameters, not run-time flags: a flag inside the MFMA loop changes the code it measures.
+// writes 1 KB of contiguous memory (wrong layout, same bytes), 2 = no output stores, 3 / 4 / 5 = 64 / 128 / 256 bytes per
+// row and instruction (wrong layout); STAMP = s_memtime per wave after the A phase and at the end.  Template parameters, not run-time flags: a flag inside the MFMA loop changes the code it measures.
 template <typename T, int KS, int NBW, int ABL = 0, bool STAMP = false>
 __global__ void __launch_bounds__(256, 2) pw_expand_kernel(const ExpandArgs g) {
-  unsigned long long t_start = 0, t_a = 0;
+  unsigned long long t_start = 0, t_a = 0, t_wait = 0;
   if constexpr (STAMP) t_start = __builtin_amdgcn_s_memtime();
   static_assert(sizeof(T) == 2 && KS % 4 == 0, "");
   constexpr int BUF = NBW * KS * 1024;  // bytes per weight buffer
-  static_assert(4 * 32 * kStagePitch <= BUF, "the A staging area lives in weight buffer 1");
+  constexpr bool LDSOUT = ABL == 0;  // production store path: full 128-byte lines through a wave-private LDS tile
+  constexpr bool HAS_TILE = pwx_has_tile(KS, NBW, ABL);  // wave-private [32 pixels][64 channels + pad] tiles behind the statistics
   extern __shared__ __align__(16) unsigned char smem[];
   float* red = reinterpret_cast<float*>(smem + 2 * BUF);  // [2][4 waves][NBW][2][32]
+  unsigned char* tbuf = smem + 2 * BUF + 2 * 4 * NBW * 64 * 4 + (threadIdx.x >> 6) * (32 * kStagePitch);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 31, lh = lane >> 5;
@@ -105,7 +114,8 @@ __global__ void __launch_bounds__(256, 2) pw_expand_kernel(const ExpandArgs g) {
   // ---- A phase: this wave's 32 pixel rows -> activated MFMA fragments in registers --------------------------------
   u32x4 afr[KS];
   {
-    unsigned char* stg = smem + BUF + wave * (32 * kStagePitch);
+    // staging rows: the output tile if this variant has one, else weight buffer 1 (free until the loop starts)
+    unsigned char* stg = HAS_TILE ? tbuf : smem + BUF + wave * (32 * kStagePitch);
     const int srow = lane >> 3, kv = (lane & 7) * 8;  // load mapping: 8 lanes cover one row's 128 bytes
     const int koff1 = g.seg[0].ch, koff2 = g.seg[0].ch + g.seg[1].ch;
     constexpr int NCH = KS / 4;  // 64-channel chunks
@@ -186,8 +196,18 @@ __global__ void __launch_bounds__(256, 2) pw_expand_kernel(const ExpandArgs g) {
 
   for (int it = 0; it < nit; ++it) {
     if (it > 0) {
-      // the DMA of this buffer was issued before the 2 * NBW output stores of the previous buffer: leave those in flight
-      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * NBW) : "memory");
+      unsigned long long t0 = 0;
+      if constexpr (STAMP) t0 = __builtin_amdgcn_s_memtime();
+      // the DMA of this buffer was issued before the output stores of the previous buffer: leave those in flight.
+      // (LDSOUT stores 4 instructions per pair of blocks, the direct path 2 per block: 2 * NBW either way, except that
+      // with one block per buffer the LDS path stores only behind every second buffer.)
+      if constexpr (LDSOUT && NBW == 1) {
+        if ((it & 1) == 0) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * NBW) : "memory");
+      }
+      if constexpr (STAMP) { t_wait += __builtin_amdgcn_s_memtime() - t0; t0 = __builtin_amdgcn_s_memtime(); }
       __builtin_amdgcn_s_barrier();
       flush_stats(it - 1);
       if (it + 1 < nit) dma(it + 1);
@@ -239,13 +259,35 @@ __global__ void __launch_bounds__(256, 2) pw_expand_kernel(const ExpandArgs g) {
         const auto a = __builtin_amdgcn_permlane32_swap(o[q], o[q + 2], false, false);
         const auto b = __builtin_amdgcn_permlane32_swap(o[q + 1], o[q + 3], false, false);
         u32x4 v = {a[0], b[0], a[1], b[1]};  // lower lanes: channels 0-7, upper lanes: channels 8-15 of that half
-        if constexpr (ABL == 0) {
+        if constexpr (LDSOUT) {
+          *reinterpret_cast<u32x4*>(tbuf + lr * kStagePitch + (((it * NBW + j) & 1) * 32 + lh * 8 + q * 4) * 2) = v;
+        } else if constexpr (ABL == 6) {  // straight from registers: 32 rows x 32 bytes per instruction
           *reinterpret_cast<u32x4*>(outp + (it * NBW + j) * 32 + q * 4) = v;
         } else if constexpr (ABL == 1) {
           T* lin = reinterpret_cast<T*>(g.out) + ((m0 + wave * 32) * g.N) + (size_t)(((it * NBW + j) * 2 + (q >> 2)) * 64 + lane) * 8;
           *reinterpret_cast<u32x4*>(lin) = v;
+        } else if constexpr (ABL >= 3) {  // same footprint, PPR 16-byte pieces per row and instruction (3: 64 B, 4: 128 B, 5: 256 B)
+          constexpr int PPR = ABL == 3 ? 4 : (ABL == 4 ? 8 : 16);
+          constexpr int IPG = PPR / 2;  // instructions per group of PPR / 4 blocks
+          const int t = ((it * NBW + j) * 2 + (q >> 2));
+          const int row = (t % IPG) * (64 / PPR) + lane / PPR, col = (t / IPG) * (PPR * 8) + (lane % PPR) * 8;
+          *reinterpret_cast<u32x4*>(reinterpret_cast<T*>(g.out) + (m0 + wave * 32 + row) * g.N + nbase + col) = v;
         } else {
           asm volatile("" ::"v"(v));
+        }
+      }
+      if constexpr (LDSOUT) {
+        if (((it * NBW + j) & 1) == 1) {  // 64 channels of the wave's 32 pixels are in the tile: 4 stores of 8 rows x 128 bytes
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's own writes (the tile is wave-private)
+          u32x4 rowv[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) rowv[i] = *reinterpret_cast<const u32x4*>(tbuf + (8 * i + (lane >> 3)) * kStagePitch + (lane & 7) * 16);
+          // the reads must have returned before another lane's next write lands on their rows: the compiler orders
+          // memory operations per thread only, so pin the order here
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          T* orow = reinterpret_cast<T*>(g.out) + (m0 + wave * 32 + (lane >> 3)) * g.N + nbase + ((it * NBW + j) >> 1) * 64 + (lane & 7) * 8;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(orow + (size_t)(8 * i) * g.N) = rowv[i];
         }
       }
     }
@@ -257,8 +299,9 @@ __global__ void __launch_bounds__(256, 2) pw_expand_kernel(const ExpandArgs g) {
     if (g.stamps && lane == 0) {
       const unsigned long long t_end = __builtin_amdgcn_s_memtime();
       const size_t wv = (size_t)blockIdx.x * 4 + wave;
-      g.stamps[2 * wv] = t_a - t_start;
-      g.stamps[2 * wv + 1] = t_end - t_a;
+      g.stamps[3 * wv] = t_a - t_start;
+      g.stamps[3 * wv + 1] = t_end - t_a;
+      g.stamps[3 * wv + 2] = t_wait;
     }
   }
 }
@@ -283,12 +326,16 @@ hipError_t launch_pack_expand(int dtype, const float* src, void* dst, int N, int
 static int g_use_pwx = 1;
 void pw_expand_enable(int v) { g_use_pwx = v; }
 
-// blocks per LDS buffer for a given K (0 = K not served)
+// 32-channel blocks per LDS buffer for a given K (0 = K not served); g_pwx_nbw overrides where the variant exists.
+// One block per buffer everywhere: the smaller LDS footprint (three workgroups per CU up to K = 256) is worth more than
+// the saved barriers (profiles/r03/pwx_nbw.txt)
+static int g_pwx_nbw = 0;
 static int nbw_for(int K) {
+  const int f = g_pwx_nbw;
   switch (K) {
-    case 128: return 4;
-    case 192: return 2;
-    case 256: return 2;
+    case 128: return (f == 1 || f == 2 || f == 4) ? f : 1;
+    case 192: return (f == 1 || f == 2) ? f : 1;
+    case 256: return (f == 1 || f == 2) ? f : 1;
     case 384: return 1;
     case 512: return 1;
   }
@@ -297,13 +344,13 @@ static int nbw_for(int K) {
 static int nsplit_for(int M, int N, int nbw) {
   // small grids: split the channels of a pixel tile over workgroups until the chip's 512 slots (2 per CU) are filled
   int ns = 1;
-  while ((long)(M / 128) * ns < 512 && (N / (32 * nbw)) % (2 * ns) == 0 && N / (32 * nbw * 2 * ns) >= 2) ns *= 2;
+  while ((long)(M / 128) * ns < 512 && (N / (32 * nbw)) % (2 * ns) == 0 && N / (32 * nbw * 2 * ns) >= 2 && (N / (2 * ns)) % 64 == 0) ns *= 2;
   return ns;
 }
 bool pw_expand_supported(int dtype, const GemmSeg* seg, int nseg, int M, int N, int K, int P) {
   if (!g_use_pwx || (dtype != 1 && dtype != 2) || nseg < 1 || nseg > 3 || P % 128 || M % P) return false;
   const int nbw = nbw_for(K);
-  if (!nbw || N % (32 * nbw)) return false;
+  if (!nbw || N % (32 * nbw) || N % 64) return false;  // pairs of 32-channel blocks leave as 128-byte lines
   int k = 0;
   for (int i = 0; i < nseg; ++i) {
     if (seg[i].ch % 64 || seg[i].act != ACT_RELU6_S6 || !seg[i].as || !seg[i].ab) return false;
@@ -316,23 +363,25 @@ static int g_pwx_ablate = 0, g_pwx_stamp = 0;
 static unsigned long long* g_pwx_stamps = nullptr;
 static size_t g_pwx_stamp_waves = 0;
 constexpr size_t kPwxStampWaves = 1u << 18;
-void pw_expand_debug(int ablate, int stamp) {
+void pw_expand_debug(int ablate, int stamp, int nbw) {
   if (ablate >= 0) g_pwx_ablate = ablate;
   if (stamp >= 0) g_pwx_stamp = stamp;
+  if (nbw >= 0) g_pwx_nbw = nbw;
 }
-hipError_t pw_expand_stamp_fetch(double* out3) {  // mean s_memtime ticks per wave of the last stamped launch: {A phase, channel loop}, waves
+hipError_t pw_expand_stamp_fetch(double* out4) {  // mean s_memtime ticks per wave of the last stamped launch: {A phase, channel loop, of which in the vmcnt wait at the top of a buffer}, waves
   if (!g_pwx_stamps || !g_pwx_stamp_waves) return hipErrorInvalidValue;
-  std::vector<unsigned long long> h(g_pwx_stamp_waves * 2);
+  std::vector<unsigned long long> h(g_pwx_stamp_waves * 3);
   if (hipError_t e = hipMemcpy(h.data(), g_pwx_stamps, h.size() * 8, hipMemcpyDeviceToHost); e != hipSuccess) return e;
-  double a = 0, b = 0;
-  for (size_t i = 0; i < g_pwx_stamp_waves; ++i) { a += (double)h[2 * i]; b += (double)h[2 * i + 1]; }
-  out3[0] = a / (double)g_pwx_stamp_waves; out3[1] = b / (double)g_pwx_stamp_waves; out3[2] = (double)g_pwx_stamp_waves;
+  double a = 0, b = 0, w = 0;
+  for (size_t i = 0; i < g_pwx_stamp_waves; ++i) { a += (double)h[3 * i]; b += (double)h[3 * i + 1]; w += (double)h[3 * i + 2]; }
+  out4[0] = a / (double)g_pwx_stamp_waves; out4[1] = b / (double)g_pwx_stamp_waves; out4[2] = w / (double)g_pwx_stamp_waves;
+  out4[3] = (double)g_pwx_stamp_waves;
   return hipSuccess;
 }
 
 template <typename T, int KS, int NBW, int ABL = 0, bool STAMP = false>
 static hipError_t launch_one(ExpandArgs a, hipStream_t s) {
-  constexpr int lds = 2 * NBW * KS * 1024 + 2 * 4 * NBW * 64 * 4;
+  constexpr int lds = pwx_lds_bytes(KS, NBW, ABL);
   static std::atomic<uint64_t> attr_done{0};
   if (hipError_t e = ensure_max_lds(reinterpret_cast<const void*>(&pw_expand_kernel<T, KS, NBW, ABL, STAMP>), lds, attr_done); e != hipSuccess) return e;
   hipLaunchKernelGGL((pw_expand_kernel<T, KS, NBW, ABL, STAMP>), dim3((unsigned)((a.M / 128) * a.nsplit)), dim3(256), lds, s, a);
@@ -347,22 +396,32 @@ static hipError_t launch_cfg(ExpandArgs a, hipStream_t s) {
     if (g_pwx_stamp) {
       const size_t waves = (size_t)(a.M / 128) * a.nsplit * 4;
       if (waves > kPwxStampWaves) return hipErrorInvalidValue;
-      if (!g_pwx_stamps && hipMalloc(reinterpret_cast<void**>(&g_pwx_stamps), kPwxStampWaves * 16) != hipSuccess) return hipErrorOutOfMemory;
+      if (!g_pwx_stamps && hipMalloc(reinterpret_cast<void**>(&g_pwx_stamps), kPwxStampWaves * 24) != hipSuccess) return hipErrorOutOfMemory;
       g_pwx_stamp_waves = waves;
       a.stamps = g_pwx_stamps;
+      if (g_pwx_ablate == 1) return launch_one<T, KS, NBW, 1, true>(a, s);
+      if (g_pwx_ablate == 2) return launch_one<T, KS, NBW, 2, true>(a, s);
       return launch_one<T, KS, NBW, 0, true>(a, s);
     }
     if (g_pwx_ablate == 1) return launch_one<T, KS, NBW, 1>(a, s);
     if (g_pwx_ablate == 2) return launch_one<T, KS, NBW, 2>(a, s);
+    if (g_pwx_ablate == 3) return launch_one<T, KS, NBW, 3>(a, s);
+    if (g_pwx_ablate == 4) return launch_one<T, KS, NBW, 4>(a, s);
+    if (g_pwx_ablate == 5) return launch_one<T, KS, NBW, 5>(a, s);
   }
+  if (g_pwx_ablate == 6) return launch_one<T, KS, NBW, 6>(a, s);  // a correct variant: available for every shape
+  if (g_pwx_ablate == 7) return launch_one<T, KS, NBW>(a, s);
+  // K = 512: the LDS tile would leave room for one workgroup per CU only (64 KB of weight buffers): registers -> HBM there
+  if constexpr (KS == 32) return launch_one<T, KS, NBW, 6>(a, s);
   return launch_one<T, KS, NBW>(a, s);
 }
 template <typename T>
 static hipError_t launch_t(const ExpandArgs& a, hipStream_t s) {
+  const int nbw = nbw_for(a.K);
   switch (a.K) {
-    case 128: return launch_cfg<T, 8, 4>(a, s);
-    case 192: return launch_cfg<T, 12, 2>(a, s);
-    case 256: return launch_cfg<T, 16, 2>(a, s);
+    case 128: return nbw == 4 ? launch_cfg<T, 8, 4>(a, s) : (nbw == 2 ? launch_cfg<T, 8, 2>(a, s) : launch_cfg<T, 8, 1>(a, s));
+    case 192: return nbw == 2 ? launch_cfg<T, 12, 2>(a, s) : launch_cfg<T, 12, 1>(a, s);
+    case 256: return nbw == 2 ? launch_cfg<T, 16, 2>(a, s) : launch_cfg<T, 16, 1>(a, s);
     case 384: return launch_cfg<T, 24, 1>(a, s);
     case 512: return launch_cfg<T, 32, 1>(a, s);
   }

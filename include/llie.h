@@ -237,7 +237,8 @@ int llie_rw_probe(const void* src, void* dst, int64_t units, int reads, int writ
  *   "irbx_dbuf" [0], "irbx_tiles" [4], "irbx_mask" [7]   variants of the recompute kernels (A/B runs)
  *   "ztot"           [1]    SE pool as fixed-point totals + fused gate kernel (0 = slab + pool / fc1 / fc2 launches)
  *   "gemm_bk" [0 = auto], "gemm_bk128" [1024 = largest grid that takes 128-wide K chunks], "dw_swap" [0],
- *   "bwd_async" [1], "wgrad_target" [1024], "pwx" [1] (activation-stationary expand GEMM, pwx.hip; 0 = tile kernel)
+ *   "bwd_async" [1], "wgrad_target" [1024], "pwx" [1] (activation-stationary expand GEMM, pwx.hip; 0 = tile kernel),
+ *   "pwx_nbw" [0 = per-K default] (32-channel blocks per weight buffer), "pwx_ablate" 6 / 7 (stores straight from registers / through the LDS tile)
  * Diagnostics whose results are WRONG or slow (timing studies only): "skip_small", "gemm_ablate", "dw_ablate",
  * "irbx_ablate", "gemm_stamp", "irbx_stamp", "pwx_ablate", "pwx_stamp".
  * Threading: the knobs are plain process-wide variables read by every forward; call llie_tune only while no other
@@ -245,7 +246,7 @@ int llie_rw_probe(const void* src, void* dst, int64_t units, int reads, int writ
 int llie_tune(const char* knob, int value);
 int llie_debug_irbx_stamps(double* out4); /* diagnostic builds: see irbx.hip (STAMP) */
 int llie_debug_gemm_stamps(double* out3); /* diagnostic builds: see gemm.hip (STAMP) */
-int llie_debug_pwx_stamps(double* out3);  /* diagnostic builds: see pwx.hip (STAMP): {A phase, channel loop} cycles per wave, waves */
+int llie_debug_pwx_stamps(double* out4);  /* diagnostic builds: see pwx.hip (STAMP): {A phase, channel loop, of which waiting for the weight DMA} cycles per wave, waves */
 
 /* Per-kernel-class timing with HIP events recorded on the launch stream (what bench.py's `roofline`
  * object is computed from).  llie_profile_begin arms recording for the classes in `class_mask`;

@@ -140,24 +140,45 @@ if __name__ == "__main__":
             for name, kind, P, segs, n in SHAPES + [("enc3.0 K1 128->512", "k1", 1024, [128], 512)]:
                 if kind != "k1" or sum(segs) < 128:
                     continue
+                L.llie_tune(b"pwx_ablate", 6)
+                ud = expand(Bx * P, segs, n, P, B=Bx)[0]
+                L.llie_tune(b"pwx_ablate", 0)
                 un, uo, nb, fl = expand(Bx * P, segs, n, P, B=Bx)
                 tot_n += un; tot_o += uo
-                print(f"B={Bx} {name:24s} pwx {un:7.1f} us {nb / un / 1e3:5.0f} GB/s {fl / un / 1e6:4.0f} TF | tile kernel {uo:7.1f} us {nb / uo / 1e3:5.0f} GB/s {fl / uo / 1e6:4.0f} TF", flush=True)
+                print(f"B={Bx} {name:24s} pwx {un:7.1f} us {nb / un / 1e3:5.0f} GB/s {fl / un / 1e6:4.0f} TF (register-direct stores {ud:7.1f} us) | tile kernel {uo:7.1f} us {nb / uo / 1e3:5.0f} GB/s {fl / uo / 1e6:4.0f} TF", flush=True)
         print(f"sum: pwx {tot_n / 2:.1f} us, tile kernel {tot_o / 2:.1f} us")
+    if "expand_nbw" in sys.argv[1:]:  # 32-channel blocks per weight buffer (LDS footprint vs barriers)
+        for rep in range(2):
+            for name, kind, P, segs, n in SHAPES + [("enc3.0 K1 128->512", "k1", 1024, [128], 512)]:
+                if kind != "k1" or sum(segs) not in (128, 192, 256):
+                    continue
+                row = []
+                for nbw in (1, 2, 4):
+                    if nbw == 4 and sum(segs) != 128:
+                        continue
+                    L.llie_tune(b"pwx_nbw", nbw)
+                    for abl in (0, 6):
+                        L.llie_tune(b"pwx_ablate", abl)
+                        row.append(f"nbw{nbw} {'tile' if abl == 0 else 'regs'} {expand(B * P, segs, n, P)[0]:6.1f}us")
+                L.llie_tune(b"pwx_nbw", 0); L.llie_tune(b"pwx_ablate", 0)
+                print(f"{name:22s} " + " | ".join(row), flush=True)
     if "expand_diag" in sys.argv[1:]:  # where the activation-stationary kernel spends its time (two representative shapes)
-        out = (C.c_double * 3)()
+        out = (C.c_double * 4)()
         for name, P, segs, n in [("dec2.0 K1 192->768", 16384, [128, 64], 768), ("dec1.0 K1 384->1536", 4096, [256, 128], 1536)]:
-            row = []
-            for abl in (0, 1, 2, 0, 1, 2):
+            for abl in (0, 6, 3, 4, 5, 1, 2):
                 L.llie_tune(b"pwx_ablate", abl)
-                un, _, nb, fl = expand(B * P, segs, n, P)
-                row.append(f"abl{abl}: {un:7.1f}us")
+                L.llie_tune(b"pwx_stamp", 0)
+                un = min(expand(B * P, segs, n, P)[0] for _ in range(2))
+                if abl > 2:  # no stamped build of these
+                    print(f"{name:22s} ablate {abl}: {un:7.1f} us", flush=True)
+                    continue
+                L.llie_tune(b"pwx_stamp", 1)
+                us = expand(B * P, segs, n, P)[0]
+                N.check(L.llie_debug_pwx_stamps(out))
+                print(f"{name:22s} ablate {abl}: {un:7.1f} us ({us:7.1f} stamped)  per wave: A phase {out[0]:8.0f} cyc, channel loop {out[1]:8.0f} cyc "
+                      f"of which {out[2]:8.0f} in the DMA / store wait ({out[3]:.0f} waves)", flush=True)
             L.llie_tune(b"pwx_ablate", 0)
-            L.llie_tune(b"pwx_stamp", 1)
-            un, _, nb, fl = expand(B * P, segs, n, P)
-            N.check(L.llie_debug_pwx_stamps(out))
             L.llie_tune(b"pwx_stamp", 0)
-            print(f"{name:22s} " + " | ".join(row) + f" | stamped {un:7.1f}us: A phase {out[0]:8.0f} cyc, channel loop {out[1]:8.0f} cyc per wave ({out[2]:.0f} waves)", flush=True)
     if "gemm_stamp" in sys.argv[1:]:
         out = (C.c_double * 3)()
         for name, kind, P, segs, n in SHAPES:
