@@ -50,6 +50,17 @@ def host_cores() -> int:
     return max(1, min(n, 16))
 
 
+def cpu_model() -> str:
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.lower().startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except Exception:  # noqa: BLE001
+        pass
+    import platform
+    return platform.processor() or "unknown"
+
+
 def cpu_baseline(variant: str, size: int, steps: int, state_dict, batch: int, budget_s: float = 24.0, train: bool = False) -> dict:
     """The CPU oracle (a restatement of the reference's PyTorch path, pinned to reference goldens)
     timed on this box's host cores on a bounded sample of the same workload (B=1 and B=min(B,4)):
@@ -98,7 +109,7 @@ def cpu_baseline(variant: str, size: int, steps: int, state_dict, batch: int, bu
     torch.set_num_threads(ncores)
     spec = oracle.make_spec(variant, size, allow_unpinned=variant in ("tiny", "base"))
     sd = {k: v.detach().cpu().float() for k, v in state_dict.items()}
-    legs = []
+    legs, kept = [], None
     for bb, share in ((1, 0.6), (min(batch, 4), 0.4)):
         if bb == 1 and legs:
             break  # batch == 1: one leg
@@ -107,8 +118,10 @@ def cpu_baseline(variant: str, size: int, steps: int, state_dict, batch: int, bu
         noise = oracle.draw_noise(bb, size, steps, seed=123)
         leg_budget = budget_s * share
         t0 = time.perf_counter()
-        oracle.enhance_ref(sd, spec, low, steps, noise)
+        ref_out = oracle.enhance_ref(sd, spec, low, steps, noise)
         first = time.perf_counter() - t0
+        if bb == 1:  # kept for the quality fields: the GPU engines are run on exactly these inputs (quality())
+            kept = {"low": low, "noise": noise, "enhanced": ref_out["enhanced"]}
         log(f"cpu_baseline: first enhance(B={bb}) took {first:.1f} s on {ncores} threads")
         if first > leg_budget / 2:
             n, el, note = 1, first, "1 cold call (a single call exceeds half this leg's time budget)"
@@ -123,10 +136,36 @@ def cpu_baseline(variant: str, size: int, steps: int, state_dict, batch: int, bu
             note = f"{n} calls after 1 warm-up"
         legs.append({"batch": bb, "images_per_sec": round(bb * n / el, 4), "note": note})
     best = max(legs, key=lambda l: l["images_per_sec"])
-    return {"value": best["images_per_sec"], "unit": "images/sec", "cores": ncores, "kind": "port",
+    return {"value": best["images_per_sec"], "unit": "images/sec", "cores": ncores, "cpu_model": cpu_model(), "kind": "port",
             "sample": f"enhance({variant}@{size}, {steps} steps, fp32) on torch CPU threads={ncores}: " +
                       "; ".join(f"B={l['batch']}: {l['images_per_sec']} img/s ({l['note']})" for l in legs),
-            "legs": legs}
+            "legs": legs, "_kept": kept}
+
+
+def quality(M, model, kept, args, dev) -> dict:
+    """The second half of BASELINE's metric ("PSNR vs CPU ref"): the engine under test and the fp32 parity engine on the
+    SAME image, weights and CPU-drawn noise as the CPU oracle's B=1 leg.  PSNR on [0, 1]-denormalised images ((x + 1) / 2,
+    low_light_diffusion.py:417-419; MAX = 1); max-abs on the clamped [-1, 1] outputs (north_star's bar for fp32: 1e-3)."""
+    import math
+    low, noise, ref = kept["low"].to(dev), torch.stack(kept["noise"]).to(dev), kept["enhanced"].double()
+
+    def psnr(x):
+        mse = ((((x.double().clamp(-1, 1) + 1) / 2) - ((ref.clamp(-1, 1) + 1) / 2)) ** 2).mean().item()
+        return 99.0 if mse == 0 else round(10 * math.log10(1.0 / mse), 2)
+    out = model.enhance(low, args.lcm_steps, noise=noise).cpu()
+    q = {"psnr_db_vs_cpu_ref": psnr(out), "max_abs_vs_cpu_ref": float(f"{(out.double() - ref).abs().max().item():.3e}"),
+         "dtype": args.dtype, "sample": "B=1, the CPU baseline leg's image, weights and CPU-drawn noise (seed 123)"}
+    if args.dtype != "fp32":
+        m32 = M.LowLightDiffusion(unet_variant=args.variant, image_size=args.image_size, num_inference_steps=args.lcm_steps,
+                                  compute_dtype="fp32", allow_unpinned_groupnorm=args.variant in ("tiny", "base"))
+        m32.load_state_dict(model.state_dict())
+        o32 = m32.to(dev).eval().enhance(low, args.lcm_steps, noise=noise).cpu()
+        q["max_abs_fp32"] = float(f"{(o32.double() - ref).abs().max().item():.3e}")
+        q["psnr_db_fp32"] = psnr(o32)
+        q["fp32_bar"] = 1e-3
+    else:
+        q["max_abs_fp32"] = q["max_abs_vs_cpu_ref"]
+    return q
 
 
 def copy_probe(native, dev, mib: int = 1024, reps: int = 10) -> float:
@@ -213,7 +252,7 @@ def train_bench(args, M, dev, rank: int, world: int) -> None:
         if not args.no_cpu_baseline and world == 1:
             extra["cpu_baseline"] = cpu_baseline(args.variant, S, 0, model.state_dict(), 1, budget_s=20.0, train=True)
         print(json.dumps({
-            "metric": "training images/sec (whole node), 256x256 'small' (BASELINE config 5)",
+            "metric": "training images/sec (whole node), 256\u00d7256 'small' (BASELINE config 5)",
             "value": round(world * B * args.steps / elapsed, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic (random-init weights, uniform image pairs)",
@@ -346,7 +385,7 @@ def main() -> None:
         dom_prof = handle.profile_report()
         dom_prof = {k: v for k, v in dom_prof.items() if k == dom_name} or dom_prof
     line = {
-        "metric": "images/sec (whole node), 256x256 4-step LCM 'small'",
+        "metric": baseline_metric(),
         "value": round(value, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": args.dtype, "data": "synthetic (random-init weights, uniform low-light batch, device noise)",
@@ -361,6 +400,8 @@ def main() -> None:
             line["roofline"] = roofline(handle, native, args, breakdown, dom_prof, elapsed / args.steps, peak_measured)
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(args.variant, S, args.lcm_steps, model.state_dict(), B)
+            kept = line["cpu_baseline"].pop("_kept")
+            line["quality"] = quality(M, model, kept, args, dev)  # "PSNR vs CPU ref": the metric's second half
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -369,6 +410,14 @@ def main() -> None:
 
 
 ALL_CLASSES = 31
+
+
+def baseline_metric() -> str:
+    """BASELINE.json's metric string, verbatim (the driver matches the bench line against it)."""
+    try:
+        return json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]
+    except Exception:  # noqa: BLE001
+        return "images/sec (whole node), 256\u00d7256 4-step LCM 'small'; PSNR vs CPU ref"
 
 
 def kernel_class_of(name: str, native) -> int:
@@ -401,7 +450,7 @@ def roofline(handle, native, args, breakdown, dom_prof, step_seconds: float, pea
     in a pass of `--steps` steps right AFTER the timed region, because the timed region itself replays a hipGraph whose
     kernels cannot be bracketed individually.  `achieved` = algorithmic bytes of that kernel's recorded launches / their
     summed device time (byte model per kernel: DESIGN.md section 3).  `traffic` = measured HBM bytes per launch from the
-    committed PMC passes of this same command (profiles/r02/pmc_traffic.json; FETCH_SIZE x2 + WRITE_SIZE, see
+    committed PMC passes of this same command (profiles/r03/pmc_traffic.json, else round 2's; FETCH_SIZE x2 + WRITE_SIZE, see
     tools/pmc_summary.py), else null.  `whole_path` is the same quotient for everything `enhance` does, measured over the
     timed region itself: lcm_steps x llie_algorithmic_bytes (SURVEY.md 8d's byte model) / the step time."""
     if not dom_prof:
@@ -410,7 +459,7 @@ def roofline(handle, native, args, breakdown, dom_prof, step_seconds: float, pea
     ms, n, nbytes = dom_prof[dom]
     achieved = nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
     traffic = None
-    pmc = os.path.join(ROOT, "profiles", "r02", "pmc_traffic.json")
+    pmc = next((q for q in (os.path.join(ROOT, "profiles", r, "pmc_traffic.json") for r in ("r03", "r02")) if os.path.exists(q)), "")
     default_cfg = (args.variant, args.image_size, args.batch, args.lcm_steps, args.dtype) == ("small", 256, 32, 4, "fp16")
     if default_cfg and os.path.exists(pmc):
         traffic = pmc_lookup(json.load(open(pmc)).get("kernels", {}), dom)
@@ -423,11 +472,17 @@ def roofline(handle, native, args, breakdown, dom_prof, step_seconds: float, pea
            "launches": n, "avg_launch_us": round(1e3 * ms / max(n, 1), 2), "alg_bytes_per_launch": int(nbytes / max(n, 1)),
            "measured_in": f"{args.steps} eager steps right after the timed region (the timed steps replay a hipGraph)",
            "forward_alg_bytes": fwd,
-           "whole_path": {"alg_bytes_per_step": args.lcm_steps * fwd, "achieved": round(whole, 1),
-                          "frac": round(whole / HBM_PEAK_GBS, 4), "frac_of_measured": round(whole / peak_measured, 4),
-                          "note": "SURVEY.md 8d byte model (2Cin+4Chid+Cout per block) over the timed region; the engine's "
-                                  "recompute kernels move less: engine_bytes_per_step",
-                          "engine_bytes_per_step": args.lcm_steps * path}}
+           # the engine runs 10 of 22 blocks in the recompute form, so SURVEY.md 8d asks for the recompute byte model here:
+           # `frac` is what the engine's own launch sequence has to move (llie_path_bytes) over the timed region; the
+           # reference-shaped (materialised) model is the secondary figure
+           "whole_path": {"model": "engine launch sequence: recompute blocks charged 3Cin+2Chid+Cout (llie_path_bytes)",
+                          "alg_bytes_per_step": args.lcm_steps * path, "achieved": round(args.lcm_steps * path / step_seconds / 1e9, 1),
+                          "frac": round(args.lcm_steps * path / step_seconds / 1e9 / HBM_PEAK_GBS, 4),
+                          "frac_of_measured": round(args.lcm_steps * path / step_seconds / 1e9 / peak_measured, 4),
+                          "materialised_model": {"note": "SURVEY.md 8d reference-shaped model (2Cin+4Chid+Cout per block: h1 written and read)",
+                                                 "alg_bytes_per_step": args.lcm_steps * fwd, "achieved": round(whole, 1),
+                                                 "frac": round(whole / HBM_PEAK_GBS, 4),
+                                                 "frac_of_measured": round(whole / peak_measured, 4)}}}
     if breakdown:  # one post-timing step with every class armed
         tot = sum(v[0] for v in breakdown.values())
         out["step_breakdown"] = {k: {"ms": round(v[0], 3), "launches": v[1], "avg_us": round(1e3 * v[0] / v[1], 2),

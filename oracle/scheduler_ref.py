@@ -5,6 +5,7 @@ to the reference (lcm_scheduler.py:23-24,53); all arithmetic is restated here.
 """
 from __future__ import annotations
 
+import math
 from dataclasses import dataclass
 from typing import List, Optional, Tuple
 
@@ -28,6 +29,12 @@ class LCMTables:
             betas = torch.linspace(beta_start, beta_end, num_train_timesteps)
         elif beta_schedule == "scaled_linear":
             betas = torch.linspace(beta_start ** 0.5, beta_end ** 0.5, num_train_timesteps) ** 2
+        elif beta_schedule == "squaredcos_cap_v2":  # _cosine_beta_schedule, lcm_scheduler.py:107-114 (s = 0.008)
+            n, s = num_train_timesteps, 0.008
+            x = torch.linspace(0, n, n + 1)
+            bar = torch.cos(((x / n) + s) / (1 + s) * math.pi * 0.5) ** 2
+            bar = bar / bar[0]
+            betas = torch.clip(1 - (bar[1:] / bar[:-1]), 0, 0.999)
         else:
             raise ValueError(f"Unknown beta schedule: {beta_schedule}")
         acp = torch.cumprod(1.0 - betas, dim=0)

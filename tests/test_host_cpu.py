@@ -126,6 +126,25 @@ def test_scheduler_tables_bit_exact(golden):
         s.set_timesteps(51)  # skipping_step 0 -> slice step cannot be zero, like the reference
 
 
+@pytest.mark.parametrize("sched", ["linear", "scaled_linear", "squaredcos_cap_v2"])
+@pytest.mark.parametrize("rescale", [False, True])
+def test_every_beta_schedule_table_bit_exact(golden, sched, rescale):
+    """The product scheduler's alpha-bar tables for all three beta schedules of lcm_scheduler.py:77-88,107-114, with and
+    without the zero-SNR rescale, against tables produced by the reference (tests/golden/schedules_kat.npz)."""
+    g = golden("schedules_kat.npz")
+    s = M.LCMScheduler(beta_schedule=sched, rescale_betas_zero_snr=rescale)
+    assert np.array_equal(s.alphas_cumprod.numpy(), g[f"acp_{sched}_{int(rescale)}"])
+    assert s.final_alpha_cumprod.item() == s.alphas_cumprod[0].item()
+    # the step scalars the engine is handed derive from that table: same values as the oracle's 0-d tensor arithmetic
+    s.set_timesteps(4)
+    tab = oracle.LCMTables.build(beta_schedule=sched, rescale_betas_zero_snr=rescale)
+    t = int(g[f"step_{sched}_{int(rescale)}_t"])
+    c = s.step_coefficients(t)
+    a_t, a_p = tab.alphas_cumprod[t], tab.alphas_cumprod[oracle.lcm_timesteps(4)[2]]
+    assert c.sqrt_alpha_t == float(a_t ** 0.5) and c.sqrt_beta_t == float((1 - a_t) ** 0.5)
+    assert c.sqrt_alpha_prev == float(a_p ** 0.5) and c.sqrt_beta_prev == float((1 - a_p) ** 0.5)
+
+
 def test_step_coefficients_match_oracle_scalars():
     s = M.LCMScheduler(rescale_betas_zero_snr=True)
     s.set_timesteps(4)

@@ -89,6 +89,26 @@ def test_add_noise_velocity(golden):
     assert np.array_equal(oracle.get_velocity(tab, x0, nz, tt).numpy(), g["get_velocity"])
 
 
+@pytest.mark.parametrize("sched", ["linear", "scaled_linear", "squaredcos_cap_v2"])
+@pytest.mark.parametrize("rescale", [False, True])
+def test_every_beta_schedule_vs_reference(golden, sched, rescale):
+    """lcm_scheduler.py:77-88,107-129: tables bit-exact, one `step` and one `add_noise` per schedule (tools/make_golden_schedules.py)."""
+    g = golden("schedules_kat.npz")
+    tag = f"{sched}_{int(rescale)}"
+    tab = oracle.LCMTables.build(beta_schedule=sched, rescale_betas_zero_snr=rescale)
+    assert np.array_equal(tab.alphas_cumprod.numpy(), g[f"acp_{tag}"])
+    ts = oracle.lcm_timesteps(4)
+    t = int(g[f"step_{tag}_t"])
+    assert t == ts[1]
+    sample = synth_input("sched2.sample", (2, 3, 8, 8), -3, 3)
+    mo = synth_input("sched2.model_output", (2, 3, 8, 8), -2, 2)
+    torch.manual_seed(77)
+    prev, x0 = oracle.lcm_step(tab, mo, t, ts[2], sample, torch.randn_like(sample))
+    assert np.array_equal(x0.numpy(), g[f"step_{tag}_x0"]) and np.array_equal(prev.numpy(), g[f"step_{tag}_prev"])
+    x0s = synth_input("sched2.x0", (3, 3, 8, 8)); nz = synth_input("sched2.noise", (3, 3, 8, 8), -2, 2)
+    assert np.array_equal(oracle.add_noise(tab, x0s, nz, torch.tensor([3, 499, 998])).numpy(), g[f"add_noise_{tag}"])
+
+
 # ------------------------------------------------------------------ per-op KATs
 def test_sinusoidal_embedding(golden):
     g = golden("ops_kat.npz")
