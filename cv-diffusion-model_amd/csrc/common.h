@@ -259,6 +259,14 @@ __device__ __forceinline__ f32x16 mfma16(typename Elem<T>::vec_t a, typename Ele
   if constexpr (std::is_same<T, half_t>::value) return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
   else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
+// one 16x16x32 MFMA on 8 packed 2-byte values per lane: lane l holds A[row l & 15][k = 8 (l >> 4) + j], B[k = 8 (l >> 4) + j][col l & 15];
+// C/D: col = l & 15, row = 4 (l >> 4) + register
+typedef float f32x4acc __attribute__((ext_vector_type(4)));
+template <typename T>
+__device__ __forceinline__ f32x4acc mfma16x16(typename Elem<T>::vec_t a, typename Elem<T>::vec_t b, f32x4acc c) {
+  if constexpr (std::is_same<T, half_t>::value) return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
 // C/D layout of every 32x32 MFMA (dtype independent): col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
 __device__ __forceinline__ int mfma_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
 

@@ -171,8 +171,11 @@ constexpr int SHP = 144;
 // ([workgroup][wave][4] = {tile prologue, MFMA phase, barrier wait, depthwise phase} cycles); never used in production.
 // ABL (diagnostic builds only): timing ablations -- 1 no h2 stores, 2 no pool sums, 4 h2 stores confined to L2, 8 no depthwise MFMAs,
 // 16 h2 stores as contiguous kilobytes (wrong layout, same bytes).
-template <typename T, int KS, bool DBUF, bool STAMP = false, int ABL = 0>
-__global__ void __launch_bounds__(256, 2) expand_dw_kernel(const IrbxArgs a, const int tiles_per_wg, const int chunks_per_wg) {
+// DWV = form of the depthwise phase: 0 = one tap per 32x32x16 MFMA (k = 16 channels of a diagonal weight matrix),
+// 1 = two taps per 16x16x32 MFMA (k = 2 taps x 16 channels): the same ds_read_b128 data operand per MFMA, half the
+// matrix-pipe time per MFMA -> 640 instead of 1 152 pipe cycles per 64-channel chunk and wave.
+template <typename T, int KS, bool DBUF, bool STAMP = false, int ABL = 0, int DWV = 1>
+__global__ void __launch_bounds__(256, (KS == 2 && !DBUF) ? 3 : 2) expand_dw_kernel(const IrbxArgs a, const int tiles_per_wg, const int chunks_per_wg) {
   constexpr int K = 16 * KS;
   constexpr int XP = (K + 8) * 2;                        // sX pixel pitch in bytes (80 / 144 / 208 / 272: conflict-free ds_read_b128)
   constexpr int XV = kXNPX * 2 * KS;                     // 16-byte vectors of one x halo tile
@@ -185,7 +188,7 @@ __global__ void __launch_bounds__(256, 2) expand_dw_kernel(const IrbxArgs a, con
   unsigned char* sH = smem;
   unsigned char* sX = smem + (DBUF ? 2 : 1) * SH_BYTES;
   T* wds = reinterpret_cast<T*>(sX + kXNPB * 32 * XP);
-  float* aff2 = reinterpret_cast<float*>(wds + 9 * a.Chid);
+  float* aff2 = reinterpret_cast<float*>(wds + 10 * a.Chid);
   float* aff1 = aff2 + 2 * a.Chid;
   float* red = aff1 + 2 * K;
 
@@ -204,7 +207,14 @@ __global__ void __launch_bounds__(256, 2) expand_dw_kernel(const IrbxArgs a, con
   const int chunk1 = chunk0 + chunks_per_wg < nchunks_all ? chunk0 + chunks_per_wg : nchunks_all;
 
   // ---- per-workgroup constants: depthwise weights (packed T), affine tables of this image
-  for (int i = tid; i < 9 * a.Chid; i += 256) wds[i] = (T)(6.f * a.wd[i]);  // the tile in LDS holds relu6(.) / 6
+  if constexpr (DWV == 1) {  // [tap pair][channel][2]: one dword = this channel's weights of taps 2 p and 2 p + 1 (tap 9 = 0)
+    for (int i = tid; i < 10 * a.Chid; i += 256) {
+      const int t = i & 1, c = (i >> 1) % a.Chid, tap = 2 * ((i >> 1) / a.Chid) + t;
+      wds[i] = tap < 9 ? (T)(6.f * a.wd[tap * a.Chid + c]) : (T)0.f;
+    }
+  } else {
+    for (int i = tid; i < 9 * a.Chid; i += 256) wds[i] = (T)(6.f * a.wd[i]);  // the tile in LDS holds relu6(.) / 6
+  }
   for (int i = tid; i < a.Chid; i += 256) {
     aff2[i] = a.as2[(size_t)b * a.Chid + i];                      // applied to acc' = acc / 6: scale unchanged,
     aff2[a.Chid + i] = a.ab2[(size_t)b * a.Chid + i] * kSixth;    // shift / 6, result clamped to [0, 1]
@@ -402,6 +412,103 @@ __global__ void __launch_bounds__(256, 2) expand_dw_kernel(const IrbxArgs a, con
       // = 36 MFMAs: the data operand is one ds_read_b128 per MFMA (lane = pixel, 8 channels), the weight operand this
       // lane's weight masked into its diagonal position (4 v_and per tap and k-step).  3 % of the MACs are useful, which
       // still equals the VALU's rate -- on a pipe that was idle, for a quarter of the VALU instructions.
+      if constexpr (DWV == 1) {
+        // ---- two taps per MFMA: D[16 ch][16 px] += A[16 ch][k] B[k][16 px], k = 16 t + c (tap slot t, channel c of the
+        // 16-channel tile).  Lane (li = lane & 15, g = lane >> 4) holds k = 8 g + j: tap slot g >> 1, channels 8 (g & 1) + j.
+        //   B: lane = output pixel li of one tile row; its 8 channels of the halo pixel under tap slot g >> 1: ONE ds_read_b128,
+        //      address = row base + this lane's tap offset (the two lane halves read different taps)
+        //   A: lane = channel li of the tile; its weight of tap slot g >> 1 at element li & 7 if (g & 1) == li >> 3, else 0
+        // A wave owns 32 channels (2 tiles) x its 4 output rows (4 pixel tiles): 8 accumulator tiles of 4 registers,
+        // 5 tap pairs (the last one half empty) = 40 MFMAs of 16 cycles.
+        typedef float f32x4v __attribute__((ext_vector_type(4)));
+        const int li = lane & 15, g = lane >> 4;
+        uint32_t amask[4];
+#pragma unroll
+        for (int d = 0; d < 4; ++d)
+          amask[d] = (((li & 7) >> 1) == d && (g & 1) == (li >> 3)) ? ((li & 1) ? 0xFFFF0000u : 0x0000FFFFu) : 0u;
+        const uint32_t* wpair = reinterpret_cast<const uint32_t*>(wds) + chunk * 64 + chb * 32 + li;  // + (pair * Chid + 16 c2)
+        const uint32_t wsel = (g >> 1) ? 0x03020302u : 0x01000100u;  // v_perm_b32 selector: this lane half's tap, duplicated
+        f32x4v dacc[2][4];
+#pragma unroll
+        for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) dacc[c2][r] = f32x4v{0.f, 0.f, 0.f, 0.f};
+        const unsigned char* bbase = buf + ((4 * pxg) * kXH_W + li) * SHP + (chb * 4 + (g & 1)) * 16;
+        const bool upper = (g >> 1) != 0;
+        vec_t bf[2][4];
+        uint32_t wq[2];
+        auto ld_step = [&](int step, vec_t (&bb)[4], uint32_t& w2) {  // step = 2 * pair + c2
+          const int pr = step >> 1, c2 = step & 1;
+          const int ta = 2 * pr, tb = 2 * pr + 1 < 9 ? 2 * pr + 1 : 8;
+          const int offa = (ta / 3) * kXH_W + ta % 3, offb = (tb / 3) * kXH_W + tb % 3;
+          const unsigned char* p0 = bbase + (upper ? offb : offa) * SHP + c2 * 32;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) bb[r] = *reinterpret_cast<const vec_t*>(p0 + r * kXH_W * SHP);
+          w2 = wpair[pr * a.Chid + 16 * c2];
+        };
+        ld_step(0, bf[0], wq[0]);
+#pragma unroll
+        for (int step = 0; step < 10; ++step) {
+          if (step + 1 < 10) ld_step(step + 1, bf[(step + 1) & 1], wq[(step + 1) & 1]);
+          __builtin_amdgcn_sched_barrier(0);  // keep the look-ahead reads above this step's MFMAs
+          const int c2 = step & 1;
+          const uint32_t wdup = __builtin_amdgcn_perm(wq[step & 1], wq[step & 1], wsel);
+          u32x4 t;
+#pragma unroll
+          for (int d = 0; d < 4; ++d) t[d] = wdup & amask[d];
+          const vec_t af = reinterpret_cast<const vec_t&>(t);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            if constexpr (!(ABL & 8)) dacc[c2][r] = mfma16x16<T>(af, bf[step & 1][r], dacc[c2][r]);
+            else asm volatile("" :: "v"(bf[step & 1][r]), "v"(af));
+          }
+        }
+        // accumulators: lane (pixel li of row r, g): channels 16 c2 + 4 g + e.  v_permlane16_swap between the two tiles gives
+        // every lane 8 consecutive channels of its pixel: even g: 4 g .. 4 g + 7, odd g: 16 + 4 (g - 1) .. 16 + 4 g + 3
+        const int choff = 8 * (g >> 1) + 16 * (g & 1);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          uint32_t p0[2], p1[2];
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            typedef T t2 __attribute__((ext_vector_type(2)));
+            t2 o0, o1;
+            o0[0] = (T)dacc[0][r][2 * j]; o0[1] = (T)dacc[0][r][2 * j + 1];
+            o1[0] = (T)dacc[1][r][2 * j]; o1[1] = (T)dacc[1][r][2 * j + 1];
+            p0[j] = *reinterpret_cast<uint32_t*>(&o0);
+            p1[j] = *reinterpret_cast<uint32_t*>(&o1);
+          }
+          const u32x2 s0 = __builtin_amdgcn_permlane16_swap(p0[0], p1[0], false, false);
+          const u32x2 s1 = __builtin_amdgcn_permlane16_swap(p0[1], p1[1], false, false);
+          const u32x4 v = {s0[0], s1[0], s0[1], s1[1]};
+          const int orow = 4 * pxg + r;
+          T* op = out + ((size_t)(y0 + orow) * a.W + x0p + li) * a.Chid + chunk * 64 + chb * 32 + choff;
+          if constexpr ((ABL & 4) != 0) op = out + ((size_t)orow * a.W + x0p + li) * a.Chid + chunk * 64 + chb * 32 + choff;
+          if constexpr (!(ABL & 1)) *reinterpret_cast<u32x4*>(op) = v;
+          else asm volatile("" :: "v"(v));
+        }
+        // SE pool partial: channel sums over the wave's 64 pixels -- the 4 rows in registers, then the 16 pixel lanes of a row by DPP
+        if (has_pool && !(ABL & 2)) {
+          float v[8];
+#pragma unroll
+          for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[4 * c2 + e] = (dacc[c2][0][e] + dacc[c2][1][e]) + (dacc[c2][2][e] + dacc[c2][3][e]);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            v[i] += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v[i]), 0x128, 0xF, 0xF, false));  // row_ror:8
+            v[i] += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v[i]), 0x124, 0xF, 0xF, false));  // row_ror:4
+            v[i] += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v[i]), 0x122, 0xF, 0xF, false));  // row_ror:2
+            v[i] += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v[i]), 0x121, 0xF, 0xF, false));  // row_ror:1
+          }
+          if (li == 0) {  // channels 16 c2 + 4 g + e of the wave's block
+            float* rp = red + (DBUF ? par : 0) * 256 + wave * 64 + 4 * g;
+            *reinterpret_cast<f32x4*>(rp) = f32x4{v[0], v[1], v[2], v[3]};
+            *reinterpret_cast<f32x4*>(rp + 16) = f32x4{v[4], v[5], v[6], v[7]};
+          }
+          pend_tile = tile; pend_chunk = chunk; pend_par = DBUF ? par : 0;
+        }
+      } else
       {
         const T* wcol = wds + chunk * 64 + chb * 32 + n;
         f32x16 dacc[2];
@@ -564,7 +671,8 @@ int irbx_stats_rows(int P) {
   return rp;
 }
 
-static int g_irbx_dbuf = 0, g_irbx_tiles = 4, g_irbx_stamp = 0, g_irbx_ablate = 0;
+static int g_irbx_dbuf = 0, g_irbx_tiles = 4, g_irbx_stamp = 0, g_irbx_ablate = 0, g_irbx_dwv = 1;
+void irbx_dwv(int v) { g_irbx_dwv = v; }
 void irbx_ablate(int v) { g_irbx_ablate = v; }
 static unsigned long long* g_irbx_dbg = nullptr;
 static size_t g_irbx_dbg_n = 0;  // entries of the last stamped launch
@@ -610,7 +718,7 @@ hipError_t launch_expand_stats(int dtype, const IrbxArgs& a, hipStream_t s) {
 
 template <typename T, int KS, bool DBUF>
 static hipError_t launch_dw_cfg(const IrbxArgs& a, hipStream_t s) {
-  const size_t lds = (size_t)(DBUF ? 2 : 1) * kXNPB * 32 * SHP + (size_t)kXNPB * 32 * (16 * KS + 8) * 2 + (size_t)9 * a.Chid * 2 +
+  const size_t lds = (size_t)(DBUF ? 2 : 1) * kXNPB * 32 * SHP + (size_t)kXNPB * 32 * (16 * KS + 8) * 2 + (size_t)10 * a.Chid * 2 +
                      (size_t)2 * a.Chid * 4 + (size_t)2 * 16 * KS * 4 + 2 * 256 * 4;
   static std::atomic<uint64_t> attr_done{0};
   if (hipError_t e = ensure_max_lds(reinterpret_cast<const void*>(&expand_dw_kernel<T, KS, DBUF>), 128 * 1024, attr_done); e != hipSuccess)
@@ -655,6 +763,13 @@ static hipError_t launch_dw_cfg(const IrbxArgs& a, hipStream_t s) {
       }
       return hipErrorInvalidValue;
     }
+  }
+  if (g_irbx_dwv == 0) {  // one tap per 32x32x16 MFMA (round 2's form), for A/B runs
+    static std::atomic<uint64_t> attr0{0};
+    if (hipError_t e = ensure_max_lds(reinterpret_cast<const void*>(&expand_dw_kernel<T, KS, DBUF, false, 0, 0>), 128 * 1024, attr0); e != hipSuccess)
+      return e;
+    hipLaunchKernelGGL((expand_dw_kernel<T, KS, DBUF, false, 0, 0>), grid, dim3(256), lds, s, a, tpw, cpw);
+    return hipGetLastError();
   }
   hipLaunchKernelGGL((expand_dw_kernel<T, KS, DBUF>), grid, dim3(256), lds, s, a, tpw, cpw);
   return hipGetLastError();

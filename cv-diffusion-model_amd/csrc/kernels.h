@@ -144,6 +144,7 @@ struct IrbxArgs {
   int ablate;                                    // timing ablations (results wrong when non-zero; 0 in production)
 };
 void irbx_ablate(int v);
+void irbx_dwv(int v);  // depthwise phase of expand_dw: 1 = two taps per 16x16x32 MFMA (default), 0 = one tap per 32x32x16 MFMA
 void irbx_stamp(int v);
 hipError_t irbx_stamp_fetch(double* out4);
 bool irbx_supported(int dtype, int Cin, int c0, int Chid, int H, int W);

@@ -234,7 +234,7 @@ int llie_rw_probe(const void* src, void* dst, int64_t units, int reads, int writ
 /* Engine knobs (process-wide; every call starts a new epoch of the hipGraph cache).  Production defaults in brackets.
  *   "enhance_split"  [2]    concurrent batch branches of the captured enhance graph (1 = one chain; env LLIE_ENHANCE_SPLIT)
  *   "irbx"           [1]    recompute form of the inverted-residual front half (0 = expand GEMM + depthwise kernel)
- *   "irbx_dbuf" [0], "irbx_tiles" [4], "irbx_mask" [7]   variants of the recompute kernels (A/B runs)
+ *   "irbx_dbuf" [0], "irbx_tiles" [4], "irbx_mask" [7], "irbx_dwv" [1]   variants of the recompute kernels (A/B runs)
  *   "ztot"           [1]    SE pool as fixed-point totals + fused gate kernel (0 = slab + pool / fc1 / fc2 launches)
  *   "gemm_bk" [0 = auto], "gemm_bk128" [1024 = largest grid that takes 128-wide K chunks], "dw_swap" [0],
  *   "bwd_async" [1], "wgrad_target" [1024], "pwx" [1] (activation-stationary expand GEMM, pwx.hip; 0 = tile kernel),
