@@ -82,6 +82,10 @@ template <typename T> __device__ __forceinline__ float round_to(float x) { retur
 __device__ __forceinline__ float relu6f(float x) { return __builtin_fminf(__builtin_fmaxf(x, 0.f), 6.f); }
 __device__ __forceinline__ float siluf(float x) { return x / (1.f + __expf(-x)); }
 __device__ __forceinline__ float sigmoidf(float x) { return 1.f / (1.f + __expf(-x)); }
+// SiLU for results that are rounded to a 2-byte type right away: v_rcp_f32 (1 ulp) instead of the IEEE division sequence
+// (v_div_scale x2, v_rcp, four FMAs, v_div_fmas, v_div_fixup: ~10 instructions per value; the output head's patch staging is
+// bound by exactly these).  The fp32 engine keeps siluf.
+__device__ __forceinline__ float siluf_fast(float x) { return x * __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
 
 __device__ __forceinline__ float apply_act(float x, int act) {
   if (act == ACT_RELU6) return relu6f(x);

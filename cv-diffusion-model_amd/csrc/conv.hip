@@ -107,6 +107,14 @@ __global__ void __launch_bounds__(256) init_conv_mfma_kernel(const InitConvArgs 
   const int x0 = tx * TW, y0 = ty * TH;
   const int Cin = a.c0 + a.c1;
   const size_t plane = (size_t)a.H * a.W;
+  // first block's weight fragments and bias up front: their (L2) latency runs under the patch staging
+  vec_t wf0[5];
+  {
+    const T* wp0 = reinterpret_cast<const T*>(a.wp);
+#pragma unroll
+    for (int s = 0; s < 5; ++s) wf0[s] = ld_vec<T>(wp0 + ((size_t)(s * 2 + (lane >> 5)) * a.Cout + (lane & 31)) * 8);
+  }
+  const float bias0 = a.bias[lane & 31];
   for (int i = tid; i < PH * PWD + 1; i += 256) {
     const int py = i / PWD, px = i % PWD;
     const int gy = y0 + py - 1, gx = x0 + px - 1;
@@ -130,8 +138,8 @@ __global__ void __launch_bounds__(256) init_conv_mfma_kernel(const InitConvArgs 
   for (int oc0 = 0; oc0 < a.Cout; oc0 += 32) {
     vec_t wf[5];
 #pragma unroll
-    for (int s = 0; s < 5; ++s) wf[s] = ld_vec<T>(wp + ((size_t)(s * 2 + h) * a.Cout + oc0 + r) * 8);
-    const float bias = a.bias[oc0 + r];
+    for (int s = 0; s < 5; ++s) wf[s] = oc0 ? ld_vec<T>(wp + ((size_t)(s * 2 + h) * a.Cout + oc0 + r) * 8) : wf0[s];
+    const float bias = oc0 ? a.bias[oc0 + r] : bias0;
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
@@ -297,6 +305,30 @@ __global__ void __launch_bounds__(256) final_conv_mfma_kernel(const FinalConvArg
 #pragma unroll
   for (int e = 0; e < 8; ++e) zero[e] = (T)0.f;
 
+  // The scheduler step's operands (this lane's pixel of the fp32 planes) and the first chunk's weight fragments are
+  // fetched before anything else: their latency then runs under the patch staging instead of after the MFMAs.
+  const size_t plane = (size_t)a.H * a.W;
+  float pre_x[2][4], pre_n[2][4];
+  if (a.fuse_step && !h) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int g = wave * 2 + t;
+      const int y = y0 + g * (32 / TW) + r / TW, x = x0 + r % TW;
+#pragma unroll
+      for (int o = 0; o < 4; ++o) {
+        pre_x[t][o] = pre_n[t][o] = 0.f;
+        if (o < a.Cout && y < a.H && x < a.W) {
+          const size_t idx = ((size_t)b * a.Cout + o) * plane + (size_t)y * a.W + x;
+          pre_x[t][o] = a.sample[idx];
+          if (!a.coef.is_last) pre_n[t][o] = a.noise[idx];
+        }
+      }
+    }
+  }
+  vec_t wf[18];
+#pragma unroll
+  for (int ks = 0; ks < 18; ++ks) wf[ks] = r < 4 ? ld_vec<T>(wp + (((size_t)ks * 2 + h) * 4 + r) * 8) : zero;
+
   for (int cc = 0; cc < a.C; cc += 32) {
     if (cc) wg_barrier();
     // stage the activated 10x34x32 patch (GroupNorm affine + SiLU applied once per element); a thread's
@@ -317,17 +349,18 @@ __global__ void __launch_bounds__(256) final_conv_mfma_kernel(const FinalConvArg
         float f[8];
         ld_f32<T>(in + ((size_t)gy * a.W + gx) * a.C + cc + cv, f);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) f[e] = siluf(f[e] * sc[e] + sh[e]);
+        for (int e = 0; e < 8; ++e) f[e] = siluf_fast(f[e] * sc[e] + sh[e]);
         v = f32_to_vec<T>(f);
       }
       *reinterpret_cast<vec_t*>(patch + pix * PIX + cv) = v;
     }
     wg_barrier();
-    // A operand: this lane's weight fragments (non-zero only for output channels r < 4)
-    vec_t wf[18];
+    // A operand: this lane's weight fragments (non-zero only for output channels r < 4); chunk 0's were fetched up front
+    if (cc) {
 #pragma unroll
-    for (int ks = 0; ks < 18; ++ks)
-      wf[ks] = r < 4 ? ld_vec<T>(wp + ((((size_t)(cc >> 5) * 18 + ks) * 2 + h) * 4 + r) * 8) : zero;
+      for (int ks = 0; ks < 18; ++ks)
+        wf[ks] = r < 4 ? ld_vec<T>(wp + ((((size_t)(cc >> 5) * 18 + ks) * 2 + h) * 4 + r) * 8) : zero;
+    }
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       const int g = wave * 2 + t;
@@ -342,7 +375,6 @@ __global__ void __launch_bounds__(256) final_conv_mfma_kernel(const FinalConvArg
     }
   }
   if (h) return;  // rows 4..7 of D (lane half 1) are padding
-  const size_t plane = (size_t)a.H * a.W;
   {
 #pragma clang fp contract(off)  // scheduler step: keep the reference's operation order (no fused multiply-adds)
 #pragma unroll
@@ -357,13 +389,13 @@ __global__ void __launch_bounds__(256) final_conv_mfma_kernel(const FinalConvArg
       const float e = acc[t][o] + a.bias[o];
       if (a.out) a.out[idx] = e;
       if (a.fuse_step) {
-        const float xv = a.sample[idx];
+        const float xv = pre_x[t][o];
         float x0v;
         if (a.coef.vpred) x0v = a.coef.sa * xv - a.coef.sb * e;
         else x0v = (xv - a.coef.sb * e) / a.coef.sa;
         if (a.coef.clamp_x0) x0v = fminf(fmaxf(x0v, -1.f), 1.f);
         float pv = x0v;
-        if (!a.coef.is_last) pv = a.coef.sap * x0v + a.coef.sbp * a.noise[idx];
+        if (!a.coef.is_last) pv = a.coef.sap * x0v + a.coef.sbp * pre_n[t][o];
         a.prev[idx] = pv;
         if (a.clamped) a.clamped[idx] = fminf(fmaxf(pv, -1.f), 1.f);
       }

@@ -195,23 +195,6 @@ __global__ void __launch_bounds__(256, 2) pw_expand_kernel(const ExpandArgs g) {
   if (nit > 1) dma(1);
 
   for (int it = 0; it < nit; ++it) {
-    if (it > 0) {
-      unsigned long long t0 = 0;
-      if constexpr (STAMP) t0 = __builtin_amdgcn_s_memtime();
-      // the DMA of this buffer was issued before the output stores of the previous buffer: leave those in flight.
-      // (LDSOUT stores 4 instructions per pair of blocks, the direct path 2 per block: 2 * NBW either way, except that
-      // with one block per buffer the LDS path stores only behind every second buffer.)
-      if constexpr (LDSOUT && NBW == 1) {
-        if ((it & 1) == 0) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-      } else {
-        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * NBW) : "memory");
-      }
-      if constexpr (STAMP) { t_wait += __builtin_amdgcn_s_memtime() - t0; t0 = __builtin_amdgcn_s_memtime(); }
-      __builtin_amdgcn_s_barrier();
-      flush_stats(it - 1);
-      if (it + 1 < nit) dma(it + 1);
-    }
     const unsigned char* wb = smem + (it & 1) * BUF + lane * 16;
     float* redw = red + (size_t)((it & 1) * 4 + wave) * NBW * 64 + lane;
 #pragma unroll
@@ -219,10 +202,22 @@ __global__ void __launch_bounds__(256, 2) pw_expand_kernel(const ExpandArgs g) {
       f32x16 acc;
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      {
+        // the weight fragments run PD reads ahead of their MFMAs (left alone, hipcc issues two reads, waits for both and
+        // multiplies twice: at two waves per SIMD the matrix pipe then waits on LDS latency in every pair)
+        constexpr int PD = KS >= 32 ? 4 : 6;
+        u32x4 wfrag[KS];
 #pragma unroll
-      for (int s = 0; s < KS; ++s) {
-        const u32x4 wfrag = *reinterpret_cast<const u32x4*>(wb + (j * KS + s) * 1024);
-        acc = mfma_u<T>(afr[s], wfrag, acc);
+        for (int s = 0; s < KS; ++s) wfrag[s] = *reinterpret_cast<const u32x4*>(wb + (j * KS + s) * 1024);
+#pragma unroll
+        for (int s = 0; s < KS; ++s) acc = mfma_u<T>(afr[s], wfrag[s], acc);
+        __builtin_amdgcn_sched_group_barrier(0x100, PD, 0);
+#pragma unroll
+        for (int s = 0; s < KS - PD; ++s) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, PD, 0);
       }
       // ---- epilogue of one 32 pixel x 32 channel block (lane = channel lr, registers = 16 pixels) ----
       u32x4 h0, h1;
@@ -290,6 +285,23 @@ __global__ void __launch_bounds__(256, 2) pw_expand_kernel(const ExpandArgs g) {
           for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(orow + (size_t)(8 * i) * g.N) = rowv[i];
         }
       }
+    }
+    if (it + 1 < nit) {  // hand over to the next buffer (kept at the END of the body: a uniform loop, nothing peeled)
+      unsigned long long t0 = 0;
+      if constexpr (STAMP) t0 = __builtin_amdgcn_s_memtime();
+      // the DMA of the next buffer was issued before this buffer's output stores: leave those in flight.
+      // (LDSOUT stores 4 instructions per pair of blocks, the direct path 2 per block: 2 * NBW either way, except that
+      // with one block per buffer the LDS path stores only behind every second buffer.)
+      if constexpr (LDSOUT && NBW == 1) {
+        if (it & 1) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * NBW) : "memory");
+      }
+      if constexpr (STAMP) t_wait += __builtin_amdgcn_s_memtime() - t0;
+      __builtin_amdgcn_s_barrier();
+      flush_stats(it);
+      if (it + 2 < nit) dma(it + 2);
     }
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");

@@ -29,6 +29,19 @@ __global__ void __launch_bounds__(256) gn_finalize_kernel(const GnFinalizeArgs a
       a.as[(size_t)b * a.C + c] = 0.f;
       a.ab[(size_t)b * a.C + c] = 0.f;
     }
+  // This kernel sits between two big launches 188 times per 4-step call and is pure latency: everything that does not
+  // depend on the statistics (norm affine, FiLM row) is fetched up front, and the slab is read with eight independent
+  // loads in flight per thread instead of one dependent load per tile (one memory round trip instead of up to 13).
+  float p_ga = 0.f, p_be = 0.f, p_fs = 0.f, p_fh = 0.f;
+  if (tid < cg) {  // cg <= 64 in every network of this engine (2048 / 32); wider groups take the loop at the end
+    p_ga = a.gamma[c_lo + tid];
+    p_be = a.beta[c_lo + tid];
+    if (a.film) {
+      const float* f = a.film + (size_t)b * a.film_stride;
+      p_fs = f[c_lo + tid];
+      p_fh = f[Creal + c_lo + tid];
+    }
+  }
   double s1 = 0.0, s2 = 0.0;
   int coff = 0;
   for (int s = 0; s < 2; ++s) {
@@ -44,11 +57,28 @@ __global__ void __launch_bounds__(256) gn_finalize_kernel(const GnFinalizeArgs a
       const int tl = w <= 256 ? tid / w : 0, cc = w <= 256 ? tid % w : tid;
       const float* base = src.slab + (size_t)b * src.ntiles * 2 * src.ch + lo;
       if (w <= 256) {
-        if (tl < per)
-          for (int t = tl; t < src.ntiles; t += per) {
+        if (tl < per) {
+          // four tiles (eight loads) per trip; the partial sums are combined in tile order, so the result does not
+          // depend on the unrolling
+          int t = tl;
+          for (; t + 3 * per < src.ntiles; t += 4 * per) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              v[2 * u] = base[(size_t)((t + u * per) * 2 + 0) * src.ch + cc];
+              v[2 * u + 1] = base[(size_t)((t + u * per) * 2 + 1) * src.ch + cc];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              s1 += (double)v[2 * u];
+              s2 += (double)v[2 * u + 1];
+            }
+          }
+          for (; t < src.ntiles; t += per) {
             s1 += (double)base[(size_t)(t * 2 + 0) * src.ch + cc];
             s2 += (double)base[(size_t)(t * 2 + 1) * src.ch + cc];
           }
+        }
       } else {
         for (int t = 0; t < src.ntiles; ++t)
           for (int c = tid; c < w; c += 256) {
@@ -80,11 +110,18 @@ __global__ void __launch_bounds__(256) gn_finalize_kernel(const GnFinalizeArgs a
   }
   for (int i = tid; i < cg; i += 256) {
     const int c = c_lo + i;
-    const float ga = a.gamma[c] * rstd;
-    float sc = ga, sh = a.beta[c] - fmean * ga;
+    float gam = p_ga, bet = p_be, ffs = p_fs, ffh = p_fh;
+    if (i >= 256) {  // groups wider than the block (not reached by the reference's variants)
+      gam = a.gamma[c]; bet = a.beta[c];
+      if (a.film) {
+        const float* f = a.film + (size_t)b * a.film_stride;
+        ffs = f[c]; ffh = f[Creal + c];
+      }
+    }
+    const float ga = gam * rstd;
+    float sc = ga, sh = bet - fmean * ga;
     if (a.film) {
-      const float* f = a.film + (size_t)b * a.film_stride;
-      const float fs = 1.f + f[c], fh = f[Creal + c];
+      const float fs = 1.f + ffs, fh = ffh;
       sc *= fs;
       sh = sh * fs + fh;
     }
@@ -1075,7 +1112,8 @@ hipError_t launch_copy_probe(const void* src, void* dst, int64_t bytes, hipStrea
 // Mixed read / write streaming probe: per step a workgroup reads R and writes W 16 KB blocks (16 bytes per lane).  The
 // write-dominated launches of this engine (the 4x expansions) are judged against what HBM sustains at THEIR read : write
 // mix, which is not the copy rate (bench.py `peak_measured`).
-template <int R, int W, bool NT>
+// MODE: 0 plain loads / stores, 1 non-temporal, 2 plain loads + write-through (sc1) stores, 3 plain loads + sc0 sc1 stores
+template <int R, int W, int MODE>
 __global__ void __launch_bounds__(256) rw_probe_kernel(const u32x4* __restrict__ src, u32x4* __restrict__ dst, int64_t units) {
   u32x4 acc = {0u, 0u, 0u, 0u};
   for (int64_t u = blockIdx.x; u < units; u += gridDim.x) {
@@ -1083,7 +1121,7 @@ __global__ void __launch_bounds__(256) rw_probe_kernel(const u32x4* __restrict__
 #pragma unroll
     for (int j = 0; j < R * 4; ++j) {
       const u32x4* p = src + (u * R * 4 + j) * 256 + threadIdx.x;
-      v[j] = NT ? __builtin_nontemporal_load(p) : *p;
+      v[j] = MODE == 1 ? __builtin_nontemporal_load(p) : *p;
     }
 #pragma unroll
     for (int j = 0; j < R * 4; ++j) acc ^= v[j];
@@ -1092,21 +1130,32 @@ __global__ void __launch_bounds__(256) rw_probe_kernel(const u32x4* __restrict__
       u32x4* p = dst + (u * W * 4 + j) * 256 + threadIdx.x;
       u32x4 o = acc;
       o[0] += (uint32_t)j;
-      if (NT) __builtin_nontemporal_store(o, p);
+      if constexpr (MODE == 1) __builtin_nontemporal_store(o, p);
+      else if constexpr (MODE == 2) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(o) : "memory");
+      else if constexpr (MODE == 3) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(p), "v"(o) : "memory");
       else *p = o;
     }
   }
   if (W == 0 && acc[0] == 0x9E3779B9u && acc[1] == 0x7F4A7C15u) dst[threadIdx.x] = acc;  // keeps the loads alive
 }
+__global__ void tiny_probe_kernel(unsigned* p) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) p[0] += 1u;
+}
 hipError_t launch_rw_probe(const void* src, void* dst, int64_t units, int r, int w, int nt, hipStream_t s) {
   const u32x4* a = reinterpret_cast<const u32x4*>(src);
   u32x4* b = reinterpret_cast<u32x4*>(dst);
   const dim3 grid(256 * 8), block(256);
-#define LLIE_RW(RR, WW)                                                                                  \
-  if (r == RR && w == WW) {                                                                              \
-    if (nt) hipLaunchKernelGGL((rw_probe_kernel<RR, WW, true>), grid, block, 0, s, a, b, units);         \
-    else hipLaunchKernelGGL((rw_probe_kernel<RR, WW, false>), grid, block, 0, s, a, b, units);           \
-    return hipGetLastError();                                                                            \
+  if (r == -1) {  // a trivial dependent launch: what a kernel boundary costs behind a write-heavy kernel (tools/gpu_rw_probe.py)
+    hipLaunchKernelGGL(tiny_probe_kernel, dim3(1), dim3(64), 0, s, reinterpret_cast<unsigned*>(dst));
+    return hipGetLastError();
+  }
+#define LLIE_RW(RR, WW)                                                                                   \
+  if (r == RR && w == WW) {                                                                               \
+    if (nt == 1) hipLaunchKernelGGL((rw_probe_kernel<RR, WW, 1>), grid, block, 0, s, a, b, units);        \
+    else if (nt == 2) hipLaunchKernelGGL((rw_probe_kernel<RR, WW, 2>), grid, block, 0, s, a, b, units);   \
+    else if (nt == 3) hipLaunchKernelGGL((rw_probe_kernel<RR, WW, 3>), grid, block, 0, s, a, b, units);   \
+    else hipLaunchKernelGGL((rw_probe_kernel<RR, WW, 0>), grid, block, 0, s, a, b, units);                \
+    return hipGetLastError();                                                                             \
   }
   LLIE_RW(1, 0) LLIE_RW(0, 1) LLIE_RW(1, 1) LLIE_RW(1, 2) LLIE_RW(1, 4) LLIE_RW(2, 1) LLIE_RW(4, 1)
 #undef LLIE_RW

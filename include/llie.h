@@ -229,6 +229,8 @@ int llie_dwconv3x3_tiles(int H, int W);
 int llie_copy_probe(const void* src, void* dst, int64_t bytes, llie_stream stream);
 /* Streaming probe with a chosen read : write mix: `units` steps, each reading `reads` and writing `writes` 16 KB blocks
  * ((reads, writes) in {(1,0),(0,1),(1,1),(1,2),(1,4),(2,1),(4,1)}; src holds units*reads, dst units*writes blocks).
+ * nontemporal: 0 plain, 1 non-temporal loads and stores, 2 write-through (sc1) stores, 3 sc0 sc1 stores.  reads == -1: a
+ * trivial dependent launch (boundary cost studies).
  * The ceiling the write-dominated 4x expansions (efficient_unet.py:174) are compared with. */
 int llie_rw_probe(const void* src, void* dst, int64_t units, int reads, int writes, int nontemporal, llie_stream stream);
 /* Engine knobs (process-wide; every call starts a new epoch of the hipGraph cache).  Production defaults in brackets.
