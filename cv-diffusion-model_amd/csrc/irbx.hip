@@ -174,7 +174,11 @@ constexpr int SHP = 144;
 // DWV = form of the depthwise phase: 0 = one tap per 32x32x16 MFMA (k = 16 channels of a diagonal weight matrix),
 // 1 = two taps per 16x16x32 MFMA (k = 2 taps x 16 channels): the same ds_read_b128 data operand per MFMA, half the
 // matrix-pipe time per MFMA -> 640 instead of 1 152 pipe cycles per 64-channel chunk and wave.
-template <typename T, int KS, bool DBUF, bool STAMP = false, int ABL = 0, int DWV = 1>
+// NCH > 0: the workgroup runs exactly NCH channel chunks per tile and the chunk loop is unrolled, which lets hipcc COUNT the
+// vector-memory operations between a prefetch and its first use: with a run-time trip count it waits vmcnt(0) for the
+// next tile's x rows and vmcnt(2) for the weight slices, i.e. for the acknowledgement of the h2 stores just issued (the
+// counter is in order) -- 37 k of 78 k cycles per wave were spent in that wait (profiles/r03/expand_dw_store_wait.txt).
+template <typename T, int KS, bool DBUF, bool STAMP = false, int ABL = 0, int DWV = 1, int NCH = 0>
 __global__ void __launch_bounds__(256, (KS == 2 && !DBUF) ? 3 : 2) expand_dw_kernel(const IrbxArgs a, const int tiles_per_wg, const int chunks_per_wg) {
   constexpr int K = 16 * KS;
   constexpr int XP = (K + 8) * 2;                        // sX pixel pitch in bytes (80 / 144 / 208 / 272: conflict-free ds_read_b128)
@@ -191,6 +195,13 @@ __global__ void __launch_bounds__(256, (KS == 2 && !DBUF) ? 3 : 2) expand_dw_ker
   float* aff2 = reinterpret_cast<float*>(wds + 10 * a.Chid);
   float* aff1 = aff2 + 2 * a.Chid;
   float* red = aff1 + 2 * K;
+  // fixed-point pool totals of this workgroup's tiles, [chunk][channel 64]: in LDS rather than in 2 KS registers of every
+  // thread -- this kernel sits exactly at an occupancy step, and a spilled register costs more than its scratch access:
+  // every reload is a vector-memory operation whose wait (vmcnt is in order) also waits for the h2 stores in flight
+  // (KS = 6 keeps them in registers: its 79 KB of LDS are two workgroups per CU only as long as nothing is added)
+  constexpr bool PACC_LDS = KS <= 4;
+  long long* pacc_lds = reinterpret_cast<long long*>(red + 2 * 256);
+  long long pacc_reg[PACC_LDS ? 1 : KS];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n = lane & 31, h = lane >> 5;
@@ -273,6 +284,14 @@ __global__ void __launch_bounds__(256, (KS == 2 && !DBUF) ? 3 : 2) expand_dw_ker
     for (int s = 0; s < KS; ++s) wf[s] = ld_vec<T>(w1 + (size_t)(chunk * 64 + chb * 32 + n) * K + 16 * s + 8 * h);
   };
   load_wf(chunk0);
+  if constexpr (NCH > 0) {
+    // settle the loads issued ahead of the tile loop here, once: otherwise hipcc merges "two operations were issued behind
+    // the prefetch" (this path) with "all of a tile's stores were" (the loop's back edge) into the smaller count
+#pragma unroll
+    for (int j = 0; j < (PREF ? XPT : 0); ++j) asm volatile("" : "+v"(reinterpret_cast<u32x4&>(raw[j])));
+#pragma unroll
+    for (int sidx = 0; sidx < KS; ++sidx) asm volatile("" : "+v"(reinterpret_cast<u32x4&>(wf[sidx])));
+  }
   wg_barrier();  // constants staged
 
   unsigned long long tk[4] = {0, 0, 0, 0}, t_prev = 0;
@@ -287,9 +306,15 @@ __global__ void __launch_bounds__(256, (KS == 2 && !DBUF) ? 3 : 2) expand_dw_ker
   const bool has_pool = a.pool != nullptr || a.pool_tot != nullptr;
   int par = 0;  // sH / red buffer parity (DBUF)
   int pend_tile = -1, pend_chunk = 0, pend_par = 0;  // pool partial waiting for its cross-wave sum
-  long long pacc[KS];  // threads 0..63: fixed-point pool totals of channel tid of chunk chunk0 + q (Chid / 64 = KS chunks at most)
+  if constexpr (PACC_LDS) {
+    if (tid < 64) {  // threads 0..63 own channel tid of every chunk (Chid / 64 = KS chunks at most); only they touch it
 #pragma unroll
-  for (int q = 0; q < KS; ++q) pacc[q] = 0;
+      for (int q = 0; q < KS; ++q) pacc_lds[q * 64 + tid] = 0;
+    }
+  } else {
+#pragma unroll
+    for (int q = 0; q < KS; ++q) pacc_reg[q] = 0;
+  }
   auto flush_pool = [&]() {  // after a barrier that follows the depthwise phase which wrote red[pend_par]
     if (pend_tile >= 0 && tid < 64) {
       const float* r = red + pend_par * 256;  // wave (chb, pxg) = chb + 2 pxg left its 32 channel sums at [wave * 64 + channel]
@@ -297,8 +322,12 @@ __global__ void __launch_bounds__(256, (KS == 2 && !DBUF) ? 3 : 2) expand_dw_ker
       const float t = r[cbb * 64 + ci] + r[(cbb + 2) * 64 + ci];
       if (a.pool_tot) {  // fixed-point, summed over this workgroup's tiles in registers: one global atomic per chunk at the end
         const long long v = __float2ll_rn(t * kPoolFixScale);
+        if constexpr (PACC_LDS) {
+          pacc_lds[(pend_chunk - chunk0) * 64 + tid] += v;
+        } else {
 #pragma unroll
-        for (int q = 0; q < KS; ++q) pacc[q] += (pend_chunk - chunk0 == q) ? v : 0ll;
+          for (int q = 0; q < KS; ++q) pacc_reg[q] += (pend_chunk - chunk0 == q) ? v : 0ll;
+        }
       } else {
         a.pool[((size_t)b * ntiles_img + pend_tile) * a.Chid + pend_chunk * 64 + tid] = t;
       }
@@ -334,7 +363,9 @@ __global__ void __launch_bounds__(256, (KS == 2 && !DBUF) ? 3 : 2) expand_dw_ker
     if (!DBUF) flush_pool();
     stamp(0);
 
-    for (int chunk = chunk0; chunk < chunk1; ++chunk) {
+#pragma unroll
+    for (int ci = 0; ci < (NCH > 0 ? NCH : chunk1 - chunk0); ++ci) {
+      const int chunk = chunk0 + ci;
       unsigned char* buf = sH + (DBUF ? par * SH_BYTES : 0);
       if (!DBUF && chunk > chunk0) {
         wg_barrier();  // previous depthwise phase done with sH
@@ -494,13 +525,19 @@ __global__ void __launch_bounds__(256, (KS == 2 && !DBUF) ? 3 : 2) expand_dw_ker
           for (int c2 = 0; c2 < 2; ++c2)
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[4 * c2 + e] = (dacc[c2][0][e] + dacc[c2][1][e]) + (dacc[c2][2][e] + dacc[c2][3][e]);
-#pragma unroll
-          for (int i = 0; i < 8; ++i) {
-            v[i] += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v[i]), 0x128, 0xF, 0xF, false));  // row_ror:8
-            v[i] += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v[i]), 0x124, 0xF, 0xF, false));  // row_ror:4
-            v[i] += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v[i]), 0x122, 0xF, 0xF, false));  // row_ror:2
-            v[i] += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v[i]), 0x121, 0xF, 0xF, false));  // row_ror:1
-          }
+          // v += rotate(v) inside each 16-lane row, as ONE v_add_f32 with a DPP source per step (through
+          // __builtin_amdgcn_update_dpp hipcc emits v_mov 0 + v_mov_dpp + add: 92 instructions for this reduction instead
+          // of 32).  The eight values are stepped together, so a register written by one statement is read again eight
+          // statements later: the VALU-write -> DPP-read hazard (2 wait states) needs no s_nop inside the strings.
+#define LLIE_DPP_STEP(ROR)                                                                                               \
+  _Pragma("unroll") for (int i = 0; i < 8; ++i)                                                                          \
+      asm volatile("v_add_f32_dpp %0, %0, %0 row_ror:" #ROR " row_mask:0xf bank_mask:0xf" : "+v"(v[i]));
+          asm volatile("s_nop 1");  // the sums just written by ordinary VALU adds: 2 wait states before the first DPP read
+          LLIE_DPP_STEP(8)
+          LLIE_DPP_STEP(4)
+          LLIE_DPP_STEP(2)
+          LLIE_DPP_STEP(1)
+#undef LLIE_DPP_STEP
           if (li == 0) {  // channels 16 c2 + 4 g + e of the wave's block
             float* rp = red + (DBUF ? par : 0) * 256 + wave * 64 + 4 * g;
             *reinterpret_cast<f32x4*>(rp) = f32x4{v[0], v[1], v[2], v[3]};
@@ -650,7 +687,7 @@ __global__ void __launch_bounds__(256, (KS == 2 && !DBUF) ? 3 : 2) expand_dw_ker
     if (a.pool_tot && tid < 64) {
 #pragma unroll
       for (int q = 0; q < KS; ++q)
-        if (chunk0 + q < chunk1) atomicAdd(a.pool_tot + (size_t)b * a.Chid + (chunk0 + q) * 64 + tid, (unsigned long long)pacc[q]);
+        if (chunk0 + q < chunk1) atomicAdd(a.pool_tot + (size_t)b * a.Chid + (chunk0 + q) * 64 + tid, (unsigned long long)(PACC_LDS ? pacc_lds[q * 64 + tid] : pacc_reg[PACC_LDS ? 0 : q]));
     }
   }
 }
@@ -671,7 +708,8 @@ int irbx_stats_rows(int P) {
   return rp;
 }
 
-static int g_irbx_dbuf = 0, g_irbx_tiles = 4, g_irbx_stamp = 0, g_irbx_ablate = 0, g_irbx_dwv = 1;
+static int g_irbx_dbuf = 0, g_irbx_tiles = 4, g_irbx_stamp = 0, g_irbx_ablate = 0, g_irbx_dwv = 1, g_irbx_nch = 0;
+void irbx_nch(int v) { g_irbx_nch = v; }
 void irbx_dwv(int v) { g_irbx_dwv = v; }
 void irbx_ablate(int v) { g_irbx_ablate = v; }
 static unsigned long long* g_irbx_dbg = nullptr;
@@ -719,7 +757,7 @@ hipError_t launch_expand_stats(int dtype, const IrbxArgs& a, hipStream_t s) {
 template <typename T, int KS, bool DBUF>
 static hipError_t launch_dw_cfg(const IrbxArgs& a, hipStream_t s) {
   const size_t lds = (size_t)(DBUF ? 2 : 1) * kXNPB * 32 * SHP + (size_t)kXNPB * 32 * (16 * KS + 8) * 2 + (size_t)10 * a.Chid * 2 +
-                     (size_t)2 * a.Chid * 4 + (size_t)2 * 16 * KS * 4 + 2 * 256 * 4;
+                     (size_t)2 * a.Chid * 4 + (size_t)2 * 16 * KS * 4 + 2 * 256 * 4 + (KS <= 4 ? (size_t)KS * 64 * 8 : 0);
   static std::atomic<uint64_t> attr_done{0};
   if (hipError_t e = ensure_max_lds(reinterpret_cast<const void*>(&expand_dw_kernel<T, KS, DBUF>), 128 * 1024, attr_done); e != hipSuccess)
     return e;
@@ -769,6 +807,13 @@ static hipError_t launch_dw_cfg(const IrbxArgs& a, hipStream_t s) {
     if (hipError_t e = ensure_max_lds(reinterpret_cast<const void*>(&expand_dw_kernel<T, KS, DBUF, false, 0, 0>), 128 * 1024, attr0); e != hipSuccess)
       return e;
     hipLaunchKernelGGL((expand_dw_kernel<T, KS, DBUF, false, 0, 0>), grid, dim3(256), lds, s, a, tpw, cpw);
+    return hipGetLastError();
+  }
+  if (cpw == nchunks && KS == nchunks && g_irbx_nch) {  // every large launch: chunk loop unrolled (counted waits, see the kernel)
+    static std::atomic<uint64_t> attrn{0};
+    if (hipError_t e = ensure_max_lds(reinterpret_cast<const void*>(&expand_dw_kernel<T, KS, DBUF, false, 0, 1, KS>), 128 * 1024, attrn); e != hipSuccess)
+      return e;
+    hipLaunchKernelGGL((expand_dw_kernel<T, KS, DBUF, false, 0, 1, KS>), grid, dim3(256), lds, s, a, tpw, cpw);
     return hipGetLastError();
   }
   hipLaunchKernelGGL((expand_dw_kernel<T, KS, DBUF>), grid, dim3(256), lds, s, a, tpw, cpw);
