@@ -2225,7 +2225,6 @@ int llie_tune(const char* knob, int value) {
   if (!strcmp(knob, "irbx_mask")) { g_irbx_mask = value; return LLIE_OK; }
   if (!strcmp(knob, "irbx_ablate")) { irbx_ablate(value); return LLIE_OK; }
   if (!strcmp(knob, "irbx_dwv")) { irbx_dwv(value); return LLIE_OK; }
-  if (!strcmp(knob, "irbx_nch")) { irbx_nch(value); return LLIE_OK; }
   if (!strcmp(knob, "gemm_stamp")) { pw_gemm_stamp(value); return LLIE_OK; }
   if (!strcmp(knob, "pwx")) { pw_expand_enable(value); return LLIE_OK; }
   if (!strcmp(knob, "pwx_ablate")) { pw_expand_debug(value, -1); return LLIE_OK; }

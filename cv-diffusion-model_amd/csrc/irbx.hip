@@ -174,11 +174,7 @@ constexpr int SHP = 144;
 // DWV = form of the depthwise phase: 0 = one tap per 32x32x16 MFMA (k = 16 channels of a diagonal weight matrix),
 // 1 = two taps per 16x16x32 MFMA (k = 2 taps x 16 channels): the same ds_read_b128 data operand per MFMA, half the
 // matrix-pipe time per MFMA -> 640 instead of 1 152 pipe cycles per 64-channel chunk and wave.
-// NCH > 0: the workgroup runs exactly NCH channel chunks per tile and the chunk loop is unrolled, which lets hipcc COUNT the
-// vector-memory operations between a prefetch and its first use: with a run-time trip count it waits vmcnt(0) for the
-// next tile's x rows and vmcnt(2) for the weight slices, i.e. for the acknowledgement of the h2 stores just issued (the
-// counter is in order) -- 37 k of 78 k cycles per wave were spent in that wait (profiles/r03/expand_dw_store_wait.txt).
-template <typename T, int KS, bool DBUF, bool STAMP = false, int ABL = 0, int DWV = 1, int NCH = 0>
+template <typename T, int KS, bool DBUF, bool STAMP = false, int ABL = 0, int DWV = 1>
 __global__ void __launch_bounds__(256, (KS == 2 && !DBUF) ? 3 : 2) expand_dw_kernel(const IrbxArgs a, const int tiles_per_wg, const int chunks_per_wg) {
   constexpr int K = 16 * KS;
   constexpr int XP = (K + 8) * 2;                        // sX pixel pitch in bytes (80 / 144 / 208 / 272: conflict-free ds_read_b128)
@@ -284,14 +280,6 @@ __global__ void __launch_bounds__(256, (KS == 2 && !DBUF) ? 3 : 2) expand_dw_ker
     for (int s = 0; s < KS; ++s) wf[s] = ld_vec<T>(w1 + (size_t)(chunk * 64 + chb * 32 + n) * K + 16 * s + 8 * h);
   };
   load_wf(chunk0);
-  if constexpr (NCH > 0) {
-    // settle the loads issued ahead of the tile loop here, once: otherwise hipcc merges "two operations were issued behind
-    // the prefetch" (this path) with "all of a tile's stores were" (the loop's back edge) into the smaller count
-#pragma unroll
-    for (int j = 0; j < (PREF ? XPT : 0); ++j) asm volatile("" : "+v"(reinterpret_cast<u32x4&>(raw[j])));
-#pragma unroll
-    for (int sidx = 0; sidx < KS; ++sidx) asm volatile("" : "+v"(reinterpret_cast<u32x4&>(wf[sidx])));
-  }
   wg_barrier();  // constants staged
 
   unsigned long long tk[4] = {0, 0, 0, 0}, t_prev = 0;
@@ -363,9 +351,10 @@ __global__ void __launch_bounds__(256, (KS == 2 && !DBUF) ? 3 : 2) expand_dw_ker
     if (!DBUF) flush_pool();
     stamp(0);
 
-#pragma unroll
-    for (int ci = 0; ci < (NCH > 0 ? NCH : chunk1 - chunk0); ++ci) {
-      const int chunk = chunk0 + ci;
+    // (Unrolling this loop lets hipcc count the memory operations between a prefetch and its use -- vmcnt(5) instead of
+    // vmcnt(2) for the weight slices -- but costs 11 spilled registers, and every spill reload waits vmcnt(0), i.e. for the
+    // h2 stores in flight: 35.7 vs 34.7 ms per step.  The run-time loop stays.)
+    for (int chunk = chunk0; chunk < chunk1; ++chunk) {
       unsigned char* buf = sH + (DBUF ? par * SH_BYTES : 0);
       if (!DBUF && chunk > chunk0) {
         wg_barrier();  // previous depthwise phase done with sH
@@ -708,8 +697,7 @@ int irbx_stats_rows(int P) {
   return rp;
 }
 
-static int g_irbx_dbuf = 0, g_irbx_tiles = 4, g_irbx_stamp = 0, g_irbx_ablate = 0, g_irbx_dwv = 1, g_irbx_nch = 0;
-void irbx_nch(int v) { g_irbx_nch = v; }
+static int g_irbx_dbuf = 0, g_irbx_tiles = 4, g_irbx_stamp = 0, g_irbx_ablate = 0, g_irbx_dwv = 1;
 void irbx_dwv(int v) { g_irbx_dwv = v; }
 void irbx_ablate(int v) { g_irbx_ablate = v; }
 static unsigned long long* g_irbx_dbg = nullptr;
@@ -807,13 +795,6 @@ static hipError_t launch_dw_cfg(const IrbxArgs& a, hipStream_t s) {
     if (hipError_t e = ensure_max_lds(reinterpret_cast<const void*>(&expand_dw_kernel<T, KS, DBUF, false, 0, 0>), 128 * 1024, attr0); e != hipSuccess)
       return e;
     hipLaunchKernelGGL((expand_dw_kernel<T, KS, DBUF, false, 0, 0>), grid, dim3(256), lds, s, a, tpw, cpw);
-    return hipGetLastError();
-  }
-  if (cpw == nchunks && KS == nchunks && g_irbx_nch) {  // every large launch: chunk loop unrolled (counted waits, see the kernel)
-    static std::atomic<uint64_t> attrn{0};
-    if (hipError_t e = ensure_max_lds(reinterpret_cast<const void*>(&expand_dw_kernel<T, KS, DBUF, false, 0, 1, KS>), 128 * 1024, attrn); e != hipSuccess)
-      return e;
-    hipLaunchKernelGGL((expand_dw_kernel<T, KS, DBUF, false, 0, 1, KS>), grid, dim3(256), lds, s, a, tpw, cpw);
     return hipGetLastError();
   }
   hipLaunchKernelGGL((expand_dw_kernel<T, KS, DBUF>), grid, dim3(256), lds, s, a, tpw, cpw);

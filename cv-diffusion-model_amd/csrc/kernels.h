@@ -166,7 +166,6 @@ hipError_t launch_pack_project(int dtype, const float* src, void* dst, int Cout,
 bool irbx_project_supported(int dtype, int Cin, int Cout, int Chid, int H, int W);
 void irbx_project_enable(int v);  // knob "irbx_proj"
 void irbx_ablate(int v);
-void irbx_nch(int v);  // expand_dw: 1 = unrolled chunk loop where a workgroup runs all chunks (default), 0 = run-time loop
 void irbx_dwv(int v);  // depthwise phase of expand_dw: 1 = two taps per 16x16x32 MFMA (default), 0 = one tap per 32x32x16 MFMA
 void irbx_stamp(int v);
 hipError_t irbx_stamp_fetch(double* out4);
