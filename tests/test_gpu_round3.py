@@ -150,3 +150,24 @@ def test_whole_network_with_and_without_activation_stationary_expand(dev, cd, mi
     # sub-batches stay bitwise identical with the new kernel in the path
     one = m.enhance(low[1:2].to(dev), 4, noise=torch.stack(noise)[:, 1:2]).cpu()
     assert torch.equal(one[0], outs[1][1])
+
+
+def test_narrow_n_tiles_on_small_grids_change_no_bit(dev):
+    """pw_gemm takes narrower N tiles when a launch has fewer than `gemm_min_grid` tiles (single images): rows per tile and the
+    k order per accumulator are unchanged, so outputs and statistics must be bit-identical with the heuristic on and off."""
+    L = N.lib()
+    spec = oracle.make_spec("small", 128)
+    sd = oracle.synth_state_dict(oracle.param_shapes(spec))
+    m = M.LowLightDiffusion(unet_variant="small", image_size=128, num_inference_steps=4, compute_dtype="fp16")
+    m.load_state_dict(sd)
+    m = m.to(dev).eval()
+    low = synth_input("r3:low128b", (1, 3, 128, 128), -1.0, -0.4)
+    noise = torch.stack(oracle.draw_noise(1, 128, 4, seed=5))
+    outs = []
+    try:
+        for knob in (192, 0, 4096):
+            N.check(L.llie_tune(b"gemm_min_grid", knob))
+            outs.append(m.enhance(low.to(dev), 4, noise=noise).cpu())
+    finally:
+        L.llie_tune(b"gemm_min_grid", 192)
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
