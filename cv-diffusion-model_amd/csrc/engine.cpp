@@ -2216,7 +2216,6 @@ int llie_tune(const char* knob, int value) {
   ++g_tune_epoch;
   if (!strcmp(knob, "gemm_bk")) { pw_gemm_force_bk(value); return LLIE_OK; }
   if (!strcmp(knob, "gemm_bk128")) { pw_gemm_bk128(value); return LLIE_OK; }
-  if (!strcmp(knob, "gemm_min_grid")) { pw_gemm_min_grid(value); return LLIE_OK; }
   if (!strcmp(knob, "skip_small")) { g_skip_small = value; return LLIE_OK; }
   if (!strcmp(knob, "ztot")) { g_ztot = value; return LLIE_OK; }
   if (!strcmp(knob, "irbx")) { g_use_irbx = value != 0; return LLIE_OK; }

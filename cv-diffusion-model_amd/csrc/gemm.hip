@@ -394,20 +394,17 @@ int pw_gemm_tile_rows(int P) { return (P % 128 == 0) ? 128 : 64; }
 int pw_gemm_ntiles(int P) { const int bm = pw_gemm_tile_rows(P); return (P + bm - 1) / bm; }  // statistics partials per image
 
 // tuning knobs for tools/gpu_tune.py (0 = automatic)
-static int g_force_bk = 0, g_bk128 = 1024, g_min_grid = 192;
-void pw_gemm_min_grid(int v) { g_min_grid = v; }
+static int g_force_bk = 0, g_bk128 = 1024;
 void pw_gemm_force_bk(int bk) { g_force_bk = bk; }
 void pw_gemm_bk128(int v) { g_bk128 = v; }
 
 template <typename T>
 static hipError_t launch_t(const GemmArgs& a, hipStream_t s) {
   const int BM = pw_gemm_tile_rows(a.P);
-  int BN = (a.N % 128 == 0) ? 128 : ((a.N % 64 == 0) ? 64 : 32);
-  // tiny launches (single images, the 1 024-pixel levels): narrower N tiles until the grid has g_min_grid workgroups -- a
-  // project GEMM of one image is 16 tiles of 128 x 128 on 256 CUs, each walking all of K alone.  The rows of a tile and the
-  // k order per accumulator do not change, so every output bit and every statistics partial is the same for any BN.
-  if (BM == 128)
-    while (BN > 32 && (long)(a.M / 128) * (a.N / BN) < g_min_grid) BN >>= 1;
+  const int BN = (a.N % 128 == 0) ? 128 : ((a.N % 64 == 0) ? 64 : 32);
+  // BN depends on N alone, never on the grid: the epilogue's statistics partials are summed per thread over rows r0 + i * (NT / (BN / VEC)),
+  // so another BN is another summation order -- narrower tiles for tiny grids (measured in round 3: -1.6 % at B = 1) made a
+  // batch differ from its halves in the last bits and were removed.
   bool k64 = sizeof(T) == 2;  // BK = 64 needs every K segment to be a multiple of 64 (2-byte T only)
   for (int i = 0; i < a.nseg; ++i) k64 = k64 && (a.seg[i].ch % 64 == 0);
   if (g_force_bk == 32) k64 = false;

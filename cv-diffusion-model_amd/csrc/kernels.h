@@ -61,7 +61,6 @@ int pw_gemm_ntiles(int P);     // stats slab tiles per image = ceil(P / BM)
 void pw_gemm_force_bk(int bk);  // tuning knob (0 = automatic)
 void pw_gemm_bk128(int max_grid);  // 128-wide K chunks for launches of up to this many workgroups (0 = never)
 void pw_gemm_debug(int v);      // timing ablations; results are wrong when non-zero
-void pw_gemm_min_grid(int v);   // launches with fewer 128-row tiles x N tiles than this take narrower N tiles (0 = never)
 
 // Expanding pointwise GEMM in activation-stationary form (pwx.hip; 2-byte T, every segment ACT_RELU6_S6):
 //   out[M][N] = sum_seg clamp01(A_seg * as + ab) . Wf^T,  Wf = the [N][K] weights times 6, pre-packed in MFMA fragment order

@@ -238,8 +238,7 @@ int llie_rw_probe(const void* src, void* dst, int64_t units, int reads, int writ
  *   "irbx"           [1]    recompute form of the inverted-residual front half (0 = expand GEMM + depthwise kernel)
  *   "irbx_dbuf" [0], "irbx_tiles" [4], "irbx_mask" [7], "irbx_dwv" [1]   variants of the recompute kernels (A/B runs)
  *   "ztot"           [1]    SE pool as fixed-point totals + fused gate kernel (0 = slab + pool / fc1 / fc2 launches)
- *   "gemm_bk" [0 = auto], "gemm_bk128" [1024 = largest grid that takes 128-wide K chunks], "gemm_min_grid" [192 = launches
- *   with fewer tiles take narrower N tiles; bits unchanged], "dw_swap" [0],
+ *   "gemm_bk" [0 = auto], "gemm_bk128" [1024 = largest grid that takes 128-wide K chunks], "dw_swap" [0],
  *   "bwd_async" [1], "wgrad_target" [1024], "pwx" [1] (activation-stationary expand GEMM, pwx.hip; 0 = tile kernel),
  *   "pwx_nbw" [0 = per-K default] (32-channel blocks per weight buffer), "pwx_ablate" 6 / 7 (stores straight from registers / through the LDS tile)
  * Diagnostics whose results are WRONG or slow (timing studies only): "skip_small", "gemm_ablate", "dw_ablate",

@@ -152,22 +152,28 @@ def test_whole_network_with_and_without_activation_stationary_expand(dev, cd, mi
     assert torch.equal(one[0], outs[1][1])
 
 
-def test_narrow_n_tiles_on_small_grids_change_no_bit(dev):
-    """pw_gemm takes narrower N tiles when a launch has fewer than `gemm_min_grid` tiles (single images): rows per tile and the
-    k order per accumulator are unchanged, so outputs and statistics must be bit-identical with the heuristic on and off."""
+@pytest.mark.parametrize("cd,pwx", [("fp16", 1), ("fp16", 0), ("bf16", 0), (None, 1)])
+def test_batch_equals_its_halves_whatever_the_grid_heuristics_choose(dev, cd, pwx):
+    """small@64 with B = 6 against B = 3 + 3: launch-size heuristics (K chunk width of pw_gemm, channel split of pw_expand)
+    fall on different sides of their thresholds for the two batch sizes on several layers; outputs must not differ in any bit
+    (a round-3 heuristic that narrowed pw_gemm's N tiles on small grids changed the statistics' summation order and was
+    removed for failing exactly this).  pwx = 0 sends the wide expands through pw_gemm too; the fp32 engine always does."""
     L = N.lib()
-    spec = oracle.make_spec("small", 128)
+    spec = oracle.make_spec("small", 64)
     sd = oracle.synth_state_dict(oracle.param_shapes(spec))
-    m = M.LowLightDiffusion(unet_variant="small", image_size=128, num_inference_steps=4, compute_dtype="fp16")
+    m = M.LowLightDiffusion(unet_variant="small", image_size=64, num_inference_steps=4, compute_dtype=cd)
     m.load_state_dict(sd)
     m = m.to(dev).eval()
-    low = synth_input("r3:low128b", (1, 3, 128, 128), -1.0, -0.4)
-    noise = torch.stack(oracle.draw_noise(1, 128, 4, seed=5))
-    outs = []
+    low = synth_input("r3:low64b", (6, 3, 64, 64), -1.0, -0.4).to(dev)
+    noise = torch.stack(oracle.draw_noise(6, 64, 4, seed=5)).to(dev)
     try:
-        for knob in (192, 0, 4096):
-            N.check(L.llie_tune(b"gemm_min_grid", knob))
-            outs.append(m.enhance(low.to(dev), 4, noise=noise).cpu())
+        N.check(L.llie_tune(b"pwx", pwx))
+        full = m.enhance(low, 4, noise=noise, return_noise_pred=True)
+        parts = [m.enhance(low[a:b], 4, noise=noise[:, a:b], return_noise_pred=True) for a, b in ((0, 3), (3, 6))]
+        one = m.enhance(low[4:5], 4, noise=noise[:, 4:5])
     finally:
-        L.llie_tune(b"gemm_min_grid", 192)
-    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+        L.llie_tune(b"pwx", 1)
+    for i in range(4):
+        assert torch.equal(torch.cat([q.noise_pred[i] for q in parts]), full.noise_pred[i]), i
+    assert torch.equal(torch.cat([q.enhanced for q in parts]), full.enhanced)
+    assert torch.equal(one, full.enhanced[4:5])
