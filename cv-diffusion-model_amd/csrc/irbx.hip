@@ -434,10 +434,14 @@ __global__ void __launch_bounds__(256, (KS == 2 && !DBUF) ? 3 : 2) expand_dw_ker
       // still equals the VALU's rate -- on a pipe that was idle, for a quarter of the VALU instructions.
       if constexpr (DWV == 1) {
         // ---- two taps per MFMA: D[16 ch][16 px] += A[16 ch][k] B[k][16 px], k = 16 t + c (tap slot t, channel c of the
-        // 16-channel tile).  Lane (li = lane & 15, g = lane >> 4) holds k = 8 g + j: tap slot g >> 1, channels 8 (g & 1) + j.
-        //   B: lane = output pixel li of one tile row; its 8 channels of the halo pixel under tap slot g >> 1: ONE ds_read_b128,
-        //      address = row base + this lane's tap offset (the two lane halves read different taps)
-        //   A: lane = channel li of the tile; its weight of tap slot g >> 1 at element li & 7 if (g & 1) == li >> 3, else 0
+        // 16-channel tile), in this order of k: lane (li = lane & 15, g = lane >> 4) holds k-slice g = tap slot g & 1, channels 8 (g >> 1) + j.
+        //   B: lane = output pixel li of one tile row; its 8 channels of the halo pixel under tap slot g & 1: ONE ds_read_b128,
+        //      address = row base + this lane's tap offset (odd and even lane quarters read different taps)
+        //   A: lane = channel li of the tile; its weight of tap slot g & 1 at element li & 7 if (g >> 1) == li >> 3, else 0
+        // (k = 16 t + c in MFMA order would put the channel half in g & 1: the 16-lane groups of a ds_read_b128 -- {0-3, 12-15,
+        // 20-27}, ... -- would then mix 8 pixels at channel slot s with 8 at slot s + 1 and collide two-way on the 144-byte
+        // pitch.  With the tap in g & 1 a group reads 16 pixels of ONE slot, 8 of them shifted by the tap distance (1 or 16
+        // pixels; equal addresses broadcast): conflict-free, 4 instead of 8 LDS cycles for each of the 40 reads.)
         // A wave owns 32 channels (2 tiles) x its 4 output rows (4 pixel tiles): 8 accumulator tiles of 4 registers,
         // 5 tap pairs (the last one half empty) = 40 MFMAs of 16 cycles.
         typedef float f32x4v __attribute__((ext_vector_type(4)));
@@ -445,16 +449,16 @@ __global__ void __launch_bounds__(256, (KS == 2 && !DBUF) ? 3 : 2) expand_dw_ker
         uint32_t amask[4];
 #pragma unroll
         for (int d = 0; d < 4; ++d)
-          amask[d] = (((li & 7) >> 1) == d && (g & 1) == (li >> 3)) ? ((li & 1) ? 0xFFFF0000u : 0x0000FFFFu) : 0u;
+          amask[d] = (((li & 7) >> 1) == d && (g >> 1) == (li >> 3)) ? ((li & 1) ? 0xFFFF0000u : 0x0000FFFFu) : 0u;
         const uint32_t* wpair = reinterpret_cast<const uint32_t*>(wds) + chunk * 64 + chb * 32 + li;  // + (pair * Chid + 16 c2)
-        const uint32_t wsel = (g >> 1) ? 0x03020302u : 0x01000100u;  // v_perm_b32 selector: this lane half's tap, duplicated
+        const uint32_t wsel = (g & 1) ? 0x03020302u : 0x01000100u;  // v_perm_b32 selector: this lane quarter's tap, duplicated
         f32x4v dacc[2][4];
 #pragma unroll
         for (int c2 = 0; c2 < 2; ++c2)
 #pragma unroll
           for (int r = 0; r < 4; ++r) dacc[c2][r] = f32x4v{0.f, 0.f, 0.f, 0.f};
-        const unsigned char* bbase = buf + ((4 * pxg) * kXH_W + li) * SHP + (chb * 4 + (g & 1)) * 16;
-        const bool upper = (g >> 1) != 0;
+        const unsigned char* bbase = buf + ((4 * pxg) * kXH_W + li) * SHP + (chb * 4 + (g >> 1)) * 16;
+        const bool upper = (g & 1) != 0;
         vec_t bf[2][4];
         uint32_t wq[2];
         auto ld_step = [&](int step, vec_t (&bb)[4], uint32_t& w2) {  // step = 2 * pair + c2
