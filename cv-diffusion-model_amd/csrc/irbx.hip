@@ -329,6 +329,11 @@ __global__ void __launch_bounds__(256, (KS == 2 && !DBUF) ? 3 : 2) expand_dw_ker
     // ---- activate this tile's x (norm1 + ReLU6) into sX, prefetch the next tile.  Every wave is past the last
     // MFMA phase of the previous tile here (the barrier that follows it), so sX is free.
     if (!PREF) load_tile(tile);
+    // Every vector-memory operation so far has to be complete here anyway (raw[] below is older than all of them), but the
+    // compiler's wait sits inside the predicated block below; said unconditionally, the chunk loop is entered with nothing
+    // pending, and the wait for the prefetched weight slices at its head becomes vmcnt(4 + ...) -- the depthwise phase's four
+    // h2 stores stay in flight -- instead of the vmcnt(0) that the merge with this path forced.
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
 #pragma unroll
     for (int j = 0; j < XPT; ++j) {
       const int v = tid + j * 256;
