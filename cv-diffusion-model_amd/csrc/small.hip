@@ -174,26 +174,54 @@ __global__ void __launch_bounds__(256) se_pool_kernel(const SeArgs a) {
   }
 }
 
-constexpr int kSeRows = 8;  // output rows per block (2 per wave)
+constexpr int kSeRows = 4;  // output rows per block = waves per block
 
 // dot products of one weight row (K contiguous T elements, 16-byte vector loads) with kSeMaxB fp32
-// vectors held in LDS; wave-wide, every lane gets the totals.
+// vectors held in LDS; wave-wide, every lane gets the totals.  These kernels are pure latency (a few KB of weights per wave
+// between two big launches, 24 times per forward): the row's vectors -- at most kSeRowVecs per lane, K <= 64 VEC kSeRowVecs =
+// 2 048 for 2-byte T, every network of this engine -- are all requested before the first is used (one memory round trip per
+// row instead of one per 512 channels); the summation order is the loop's.
+constexpr int kSeRowVecs = 4;
 template <typename T>
-__device__ __forceinline__ void se_row_dots(const T* wrow, const float* vecs, int K, int nb, int lane, float* out) {
+struct SeRow {  // the vectors of one weight row held by this lane
+  typename Elem<T>::vec_t wv[kSeRowVecs];
+  bool pre;
+};
+template <typename T>
+__device__ __forceinline__ void se_row_fetch(SeRow<T>& r, const T* wrow, int K, int lane) {
   constexpr int VEC = Elem<T>::VEC;
+  const int kvec = K / VEC * VEC;
+  r.pre = kvec <= 64 * VEC * kSeRowVecs;
+  if (r.pre) {
+#pragma unroll
+    for (int u = 0; u < kSeRowVecs; ++u)
+      if ((lane + 64 * u) * VEC < kvec) r.wv[u] = ld_vec<T>(wrow + (lane + 64 * u) * VEC);
+  }
+}
+template <typename T>
+__device__ __forceinline__ void se_row_dots(const SeRow<T>& r, const T* wrow, const float* vecs, int K, int nb, int lane, float* out) {
+  constexpr int VEC = Elem<T>::VEC;
+  typedef typename Elem<T>::vec_t vec_t;
   float acc[kSeMaxB];
 #pragma unroll
   for (int q = 0; q < kSeMaxB; ++q) acc[q] = 0.f;
   const int kvec = K / VEC * VEC;
-  for (int k = lane * VEC; k < kvec; k += 64 * VEC) {
+  auto use = [&](const vec_t& wv, int k) {
     float w[VEC];
-    ld_f32<T>(wrow + k, w);
+    vec_to_f32<T>(wv, w);
 #pragma unroll
     for (int q = 0; q < kSeMaxB; ++q)
       if (q < nb) {
 #pragma unroll
         for (int e = 0; e < VEC; ++e) acc[q] += w[e] * vecs[q * K + k + e];
       }
+  };
+  if (r.pre) {
+#pragma unroll
+    for (int u = 0; u < kSeRowVecs; ++u)
+      if ((lane + 64 * u) * VEC < kvec) use(r.wv[u], (lane + 64 * u) * VEC);
+  } else {
+    for (int k = lane * VEC; k < kvec; k += 64 * VEC) use(ld_vec<T>(wrow + k), k);
   }
   for (int k = kvec + lane; k < K; k += 64) {  // tail (K not a multiple of the vector width)
     const float w = (float)wrow[k];
@@ -205,11 +233,20 @@ __device__ __forceinline__ void se_row_dots(const T* wrow, const float* vecs, in
   for (int q = 0; q < kSeMaxB; ++q) out[q] = wave_sum(acc[q]);
 }
 
+// One output row per wave; the row's weights are requested first, so they travel while the block stages its operand.
 template <typename T>
 __global__ void __launch_bounds__(256) se_fc1_kernel(const SeArgs a) {
   extern __shared__ float smean[];  // [nb][C] means of this block's image chunk
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b0 = blockIdx.y * kSeMaxB, nb = min(kSeMaxB, a.B - b0);
+  const T* w1 = reinterpret_cast<const T*>(a.w1);
+  const int j = blockIdx.x * kSeRows + wave;
+  SeRow<T> row;
+  float bj = 0.f;
+  if (j < a.Cs) {
+    se_row_fetch<T>(row, w1 + (size_t)j * a.C, a.C, lane);
+    bj = a.b1[j];
+  }
   if (a.tot) {  // fixed-point channel totals straight from the depthwise kernel: no pool pass
     const double inv = 1.0 / ((double)a.P * (double)kPoolFixScale);
     for (int i = tid; i < nb * a.C; i += 256) smean[i] = (float)((double)(long long)a.tot[(size_t)b0 * a.C + i] * inv);
@@ -217,16 +254,12 @@ __global__ void __launch_bounds__(256) se_fc1_kernel(const SeArgs a) {
     for (int i = tid; i < nb * a.C; i += 256) smean[i] = a.mean[(size_t)b0 * a.C + i];
   }
   wg_barrier();
-  const T* w1 = reinterpret_cast<const T*>(a.w1);
-  for (int jj = wave; jj < kSeRows; jj += 4) {
-    const int j = blockIdx.x * kSeRows + jj;
-    if (j >= a.Cs) break;
-    float v[kSeMaxB];
-    se_row_dots<T>(w1 + (size_t)j * a.C, smean, a.C, nb, lane, v);
+  if (j >= a.Cs) return;
+  float v[kSeMaxB];
+  se_row_dots<T>(row, w1 + (size_t)j * a.C, smean, a.C, nb, lane, v);
 #pragma unroll
-    for (int q = 0; q < kSeMaxB; ++q)
-      if (q < nb && lane == 0) a.hid[(size_t)(b0 + q) * a.Cs + j] = relu6f(v[q] + a.b1[j]);
-  }
+  for (int q = 0; q < kSeMaxB; ++q)
+    if (q < nb && lane == 0) a.hid[(size_t)(b0 + q) * a.Cs + j] = relu6f(v[q] + bj);
 }
 
 template <typename T>
@@ -234,18 +267,22 @@ __global__ void __launch_bounds__(256) se_fc2_kernel(const SeArgs a) {
   extern __shared__ float shid[];  // [nb][Cs]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b0 = blockIdx.y * kSeMaxB, nb = min(kSeMaxB, a.B - b0);
+  const T* w2 = reinterpret_cast<const T*>(a.w2);
+  const int c = blockIdx.x * kSeRows + wave;
+  SeRow<T> row;
+  float bc = 0.f;
+  if (c < a.C) {
+    se_row_fetch<T>(row, w2 + (size_t)c * a.Cs, a.Cs, lane);
+    bc = a.b2[c];
+  }
   for (int i = tid; i < nb * a.Cs; i += 256) shid[i] = a.hid[(size_t)b0 * a.Cs + i];
   wg_barrier();
-  const T* w2 = reinterpret_cast<const T*>(a.w2);
-  for (int cc = wave; cc < kSeRows; cc += 4) {
-    const int c = blockIdx.x * kSeRows + cc;
-    if (c >= a.C) break;
-    float v[kSeMaxB];
-    se_row_dots<T>(w2 + (size_t)c * a.Cs, shid, a.Cs, nb, lane, v);
+  if (c >= a.C) return;
+  float v[kSeMaxB];
+  se_row_dots<T>(row, w2 + (size_t)c * a.Cs, shid, a.Cs, nb, lane, v);
 #pragma unroll
-    for (int q = 0; q < kSeMaxB; ++q)
-      if (q < nb && lane == 0) a.gate[(size_t)(b0 + q) * a.C + c] = sigmoidf(v[q] + a.b2[c]);
-  }
+  for (int q = 0; q < kSeMaxB; ++q)
+    if (q < nb && lane == 0) a.gate[(size_t)(b0 + q) * a.C + c] = sigmoidf(v[q] + bc);
 }
 
 // Inference form of the whole SE branch in one launch.  The depthwise kernels leave fixed-point channel totals
