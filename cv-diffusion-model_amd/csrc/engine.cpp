@@ -544,6 +544,7 @@ int build_module(llie_ctx* c) {
 // Recompute form (irbx.hip: statistics-only expand + tile-fused expand/depthwise): default for the
 // inference path of 2-byte engines wherever irbx_supported(); llie_tune("irbx", 0) restores the unfused pair.
 int g_use_irbx = getenv("LLIE_NO_IRBX") ? 0 : 1;
+int g_gram = 1;  // norm2 statistics of the recompute form from the Gram matrix of the block input (gram.hip); 0 = expand_stats
 int g_ztot = 1;  // SE pool as fixed-point totals + fused gate kernel (llie_tune("ztot", 0): the slab + three launches, as in training)
 int g_skip_small = 0;  // timing ablation only (results are garbage): bit 0 no gn_finalize launches, bit 1 no SE launches
 int g_irbx_mask = 0x7;  // debug: which input widths may take the recompute form (bit 0: 32, bit 1: 64, bit 2: 96 channels)
@@ -681,13 +682,28 @@ struct Run {
     Tens h1;
     h1.C = w.hid; h1.Cr = w.hid_r; h1.H = H; h1.W = W; h1.ntiles = fusedx ? P / irbx_stats_rows(P) : pw_gemm_ntiles(P); h1.valid = true;
     h1.off = fusedx ? 0 : ar->alloc((size_t)B * P * w.hid * es());
-    h1.slab = ar->alloc((size_t)B * h1.ntiles * 2 * w.hid * 4);
+    // norm2's statistics of the recompute form: from the Gram matrix of the activated input (gram.hip) -- the statistics
+    // pass is then a plain read of x -- or, knob "gram" = 0, from a second run of the expand GEMM (expand_stats)
+    // (from 32 768 pixels per image on: below, the workgroup epilogue and the last-ticket sum outweigh the saved MFMAs --
+    // measured at B = 1 and B = 32; the rule must not depend on the batch, it fixes the statistics' summation order)
+    const bool gram = fusedx && g_gram && (P >= 32768 || g_gram > 1) && gram_supported(dt, w.cin, x0.C, P);
+    h1.slab = gram ? 0 : ar->alloc((size_t)B * h1.ntiles * 2 * w.hid * 4);
+    const size_t gpart = gram ? ar->alloc((size_t)B * gram_part_floats(w.cin, P) * 4) : 0;
+    const size_t gtot = gram ? ar->alloc((size_t)B * (w.cin * w.cin + w.cin) * 4) : 0;
+    const size_t gtick = gram ? ztake((size_t)B * 4) : 0;
     IrbxArgs xa{};
     if (fusedx && !dry) {
       xa.x0 = p(x0.off); xa.c0 = x0.C; xa.x1 = x1 ? p(x1->off) : nullptr; xa.c1 = x1 ? x1->C : 0;
       xa.as1 = p<float>(as1); xa.ab1 = p<float>(ab1); xa.w1 = wptr(w.w_expand); xa.wd = wptr<float>(w.w_dw);
-      xa.stats = p<float>(h1.slab); xa.B = B; xa.H = H; xa.W = W; xa.Chid = w.hid;
-      timed(LLIE_K_GEMM, ((int64_t)M * w.cin + (int64_t)w.hid * w.cin) * (int64_t)es(), [&] { return launch_expand_stats(dt, xa, s); });
+      xa.stats = gram ? nullptr : p<float>(h1.slab); xa.B = B; xa.H = H; xa.W = W; xa.Chid = w.hid;
+      if (gram) {
+        GramArgs ga{};
+        ga.x0 = xa.x0; ga.x1 = xa.x1; ga.c0 = xa.c0; ga.c1 = xa.c1; ga.as1 = xa.as1; ga.ab1 = xa.ab1;
+        ga.part = p<float>(gpart); ga.gtot = p<float>(gtot); ga.tickets = p<unsigned int>(gtick); ga.B = B; ga.P = P;
+        timed(LLIE_K_GEMM, (int64_t)M * w.cin * (int64_t)es(), [&] { return launch_gram_stats(dt, ga, s); });
+      } else {
+        timed(LLIE_K_GEMM, ((int64_t)M * w.cin + (int64_t)w.hid * w.cin) * (int64_t)es(), [&] { return launch_expand_stats(dt, xa, s); });
+      }
     } else if (!dry) {
       GemmArgs g{};
       const int act1 = s6 ? ACT_RELU6_S6 : ACT_RELU6;
@@ -716,7 +732,21 @@ struct Run {
     // unfused depthwise of a 2-byte inference engine: tables / 6 and clamp01 in its prologue too (DwArgs::s6); the
     // recompute kernel takes the plain tables (it rescales the shift itself: its accumulators are already / 6)
     const bool s6dw = s6 && !fusedx;
-    gn(h1, nullptr, w.n2g, w.n2b, film ? film + w.film_off : nullptr, film_stride, as2, ab2, &rec.n2, s6dw ? 1.f / 6.f : 0.f);
+    if (gram) {
+      as2 = ar->alloc((size_t)B * w.hid * 4);
+      ab2 = ar->alloc((size_t)B * w.hid * 4);
+      if (!dry && !(g_skip_small & 1)) {
+        GramFinalizeArgs fa{};
+        fa.gtot = p<float>(gtot); fa.w1 = wptr(w.w_expand); fa.K = w.cin; fa.Chid = w.hid; fa.groups = gn_groups(w.hid); fa.P = P; fa.B = B;
+        fa.gamma = wptr<float>(w.n2g); fa.beta = wptr<float>(w.n2b);
+        fa.film = film ? film + w.film_off : nullptr; fa.film_stride = film_stride; fa.eps = 1e-5f;
+        fa.as = p<float>(as2); fa.ab = p<float>(ab2); fa.post_scale = 0.f;
+        timed(LLIE_K_OTHER, (int64_t)B * w.hid * 8, [&] { return launch_gram_finalize(dt, fa, s); }, "gram_finalize_kernel");
+      }
+      rel(gpart);
+    } else {
+      gn(h1, nullptr, w.n2g, w.n2b, film ? film + w.film_off : nullptr, film_stride, as2, ab2, &rec.n2, s6dw ? 1.f / 6.f : 0.f);
+    }
     // K2: depthwise with affine + ReLU6 prologue and SE pool partials
     const int dnt = fusedx ? irbx_pool_tiles(H, W) : dwconv_ntiles(H, W);
     const size_t h2 = ar->alloc((size_t)M * w.hid * es());
@@ -741,7 +771,7 @@ struct Run {
     }
     rel(as1); rel(ab1);
     if (!fusedx) rel(h1.off);
-    rel(h1.slab);
+    if (gram) rel(gtot); else rel(h1.slab);
     rel(as2); rel(ab2);
     // SE MLP
     const size_t sehid = ar->alloc((size_t)B * w.sq * 4), gate = ar->alloc((size_t)B * w.hid * 4);
@@ -2115,6 +2145,17 @@ int llie_enhance(llie_ctx* c, const float* low, const float* noise, const int64_
   return LLIE_OK;
 }
 
+int llie_gram_stats(int dtype, const void* x0, int c0, const void* x1, int c1, const float* scale, const float* bias, int batch, int pixels,
+                    float* part, float* gtot, unsigned int* tickets, llie_stream stream) {
+  GramArgs a{};
+  a.x0 = x0; a.x1 = x1; a.c0 = c0; a.c1 = c1; a.as1 = scale; a.ab1 = bias; a.part = part; a.gtot = gtot; a.tickets = tickets; a.B = batch; a.P = pixels;
+  if (!gram_supported(dtype, c0 + c1, c0, pixels)) { set_err("gram_stats: K in {32, 64, 96}, 2-byte dtype, pixels a multiple of 512"); return LLIE_ERR_SHAPE; }
+  hipError_t e = launch_gram_stats(dtype, a, reinterpret_cast<hipStream_t>(stream));
+  if (e != hipSuccess) { set_err("gram_stats: %s", hipGetErrorString(e)); return e == hipErrorInvalidValue ? LLIE_ERR_ARG : (int)e; }
+  return LLIE_OK;
+}
+int64_t llie_gram_part_floats(int K, int pixels) { return (K == 32 || K == 64 || K == 96) && pixels > 0 && pixels % 512 == 0 ? (int64_t)gram_part_floats(K, pixels) : LLIE_ERR_ARG; }
+
 // ---- kernel-level entry points (unit tests, tuning): thin wrappers over the launch API
 int llie_pw_gemm(int dtype, const llie_gemm_seg* segs, int nseg, const void* w, const float* bias, const void* residual,
                  void* out, float* stats, int M, int N, int P, llie_stream stream) {
@@ -2218,6 +2259,7 @@ int llie_tune(const char* knob, int value) {
   if (!strcmp(knob, "gemm_bk128")) { pw_gemm_bk128(value); return LLIE_OK; }
   if (!strcmp(knob, "skip_small")) { g_skip_small = value; return LLIE_OK; }
   if (!strcmp(knob, "ztot")) { g_ztot = value; return LLIE_OK; }
+  if (!strcmp(knob, "gram")) { g_gram = value; return LLIE_OK; }
   if (!strcmp(knob, "irbx")) { g_use_irbx = value != 0; return LLIE_OK; }
   if (!strcmp(knob, "irbx_dbuf")) { irbx_tune(value, 0); return LLIE_OK; }
   if (!strcmp(knob, "irbx_tiles")) { irbx_tune(-1, value); return LLIE_OK; }

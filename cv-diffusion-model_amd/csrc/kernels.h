@@ -128,6 +128,31 @@ struct DwArgs {
 };
 hipError_t launch_dwconv3x3(int dtype, const DwArgs& a, hipStream_t s);
 
+// GroupNorm-2 statistics of the recompute form from the Gram matrix of the activated block input (gram.hip, 2-byte T).
+struct GramArgs {
+  const void* x0; const void* x1; int c0, c1;   // block input (virtual concat), K = c0 + c1 in {32, 64, 96}, c0 % 8 == 0
+  const float* as1; const float* ab1;            // [B][K] GroupNorm-1 affine DIVIDED BY 6 (a' = clamp01(.) = relu6 / 6)
+  float* part;                                    // [B][P / gram_rows][upper 32 x 32 blocks x 1024 + K] workgroup partials
+  float* gtot;                                    // [B][K * K + K]: G = sum_px a' a'^T in full, then m = sum_px a'
+  unsigned int* tickets;                          // [B], zero at launch (the kernel leaves them zero)
+  int B, P, RP;                                   // RP is set by the launcher (gram_rows)
+};
+struct GramFinalizeArgs {
+  const float* gtot;   // as written by gram_stats_kernel
+  const void* w1;      // [Chid][K] T: the expand weights the main pass multiplies with
+  int K, Chid, groups, P, B;
+  const float* gamma; const float* beta;   // norm2
+  const float* film; int64_t film_stride;  // null or [rows][2 Chid]
+  float eps;
+  float* as; float* ab;                    // [B][Chid]
+  float post_scale;
+};
+int gram_rows(int K, int P);
+size_t gram_part_floats(int K, int P);
+bool gram_supported(int dtype, int K, int c0, int P);
+hipError_t launch_gram_stats(int dtype, const GramArgs& a, hipStream_t s);
+hipError_t launch_gram_finalize(int dtype, const GramFinalizeArgs& a, hipStream_t s);
+
 // Recompute form of the block's front half (irbx.hip, 2-byte T): expand_stats writes only h1's statistics slab
 // ([B][P / irbx_stats_rows(P)][2][Chid]), expand_dw produces h2 and the SE pool slab ([B][irbx_pool_tiles][Chid]).
 struct IrbxArgs {

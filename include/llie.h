@@ -221,6 +221,14 @@ int llie_pw_gemm_tile_rows(int P);
  *   from an earlier call with the same weights -- the GEMM alone).  stats: as llie_pw_gemm. */
 int llie_pw_expand(int dtype, const llie_gemm_seg* segs, int nseg, const float* w32, void* wpack, void* out, float* stats,
                    int M, int N, int P, llie_stream stream);
+/* Statistics pass of the recompute form of InvertedResidualBlock (efficient_unet.py:207-212) on its own: Gram matrix
+ * G = sum_px a' a'^T and column sums m = sum_px a' of a' = clamp01(x * scale + bias) rounded to the compute type, per image
+ * (gram.hip).  x0 / x1: NHWC [batch][pixels][c0 / c1] of the compute type (x1 may be NULL with c1 = 0), c0 + c1 in {32, 64, 96},
+ * c0 % 8 == 0, pixels % 512 == 0; scale / bias [batch][c0 + c1] fp32; part: scratch of batch * llie_gram_part_floats floats;
+ * gtot out: [batch][K * K + K] fp32 (G row-major, then m); tickets: [batch] uint32, zero on entry (left zero). */
+int llie_gram_stats(int dtype, const void* x0, int c0, const void* x1, int c1, const float* scale, const float* bias, int batch,
+                    int pixels, float* part, float* gtot, unsigned int* tickets, llie_stream stream);
+int64_t llie_gram_part_floats(int K, int pixels);
 int llie_dwconv3x3(int dtype, const void* in, void* out, const float* scale, const float* bias, const float* w9c,
                    float* pool, int B, int H, int W, int C, llie_stream stream);
 int llie_dwconv3x3_tiles(int H, int W);
@@ -240,6 +248,7 @@ int llie_rw_probe(const void* src, void* dst, int64_t units, int reads, int writ
  *   "ztot"           [1]    SE pool as fixed-point totals + fused gate kernel (0 = slab + pool / fc1 / fc2 launches)
  *   "gemm_bk" [0 = auto], "gemm_bk128" [1024 = largest grid that takes 128-wide K chunks], "dw_swap" [0],
  *   "bwd_async" [1], "wgrad_target" [1024], "pwx" [1] (activation-stationary expand GEMM, pwx.hip; 0 = tile kernel),
+ *   "gram" [1] (norm2 statistics of the recompute form from the Gram matrix of the block input, gram.hip; 0 = expand_stats),
  *   "pwx_nbw" [0 = per-K default] (32-channel blocks per weight buffer), "pwx_ablate" 6 / 7 (stores straight from registers / through the LDS tile)
  * Diagnostics whose results are WRONG or slow (timing studies only): "skip_small", "gemm_ablate", "dw_ablate",
  * "irbx_ablate", "gemm_stamp", "irbx_stamp", "pwx_ablate", "pwx_stamp".

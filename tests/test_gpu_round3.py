@@ -177,3 +177,81 @@ def test_batch_equals_its_halves_whatever_the_grid_heuristics_choose(dev, cd, pw
         assert torch.equal(torch.cat([q.noise_pred[i] for q in parts]), full.noise_pred[i]), i
     assert torch.equal(torch.cat([q.enhanced for q in parts]), full.enhanced)
     assert torch.equal(one, full.enhanced[4:5])
+
+
+# ------------------------------------------------------------------ GroupNorm-2 statistics from the Gram matrix (gram.hip)
+@pytest.mark.parametrize("dtype,tdt", [(1, torch.float16), (2, torch.bfloat16)])
+@pytest.mark.parametrize("c0,c1,P,B", [(32, 0, 4096, 3), (32, 32, 16384, 2), (64, 32, 8192, 2), (64, 0, 512, 3), (16, 16, 1024, 2), (96, 0, 65536, 1)])
+def test_gram_stats_vs_torch(dev, dtype, tdt, c0, c1, P, B):
+    """llie_gram_stats against a float64 restatement: G = sum_px a a^T, m = sum_px a of a = clamp01(x * s + b) rounded to the
+    compute type (the operand relu6(norm1(x)) / 6 of the expand GEMM, efficient_unet.py:207-208); concat inputs, one to 512
+    workgroup partials per image; a single image alone gives the same bits; the tickets are left zero."""
+    L = N.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    K = c0 + c1
+    g = torch.Generator().manual_seed(K * 1000 + P)
+    x0 = (torch.randn(B, P, c0, generator=g) * 1.5).to(tdt)
+    x1 = (torch.randn(B, P, c1, generator=g) * 1.5).to(tdt) if c1 else None
+    sc = (torch.rand(B, K, generator=g) + 0.5) / 6
+    bi = (torch.randn(B, K, generator=g) * 0.5 + 0.4) / 6
+
+    def run(sl):
+        nb = sl.stop - sl.start
+        d0 = x0[sl].contiguous().to(dev)
+        d1 = x1[sl].contiguous().to(dev) if c1 else None
+        s_d, b_d = sc[sl].contiguous().to(dev), bi[sl].contiguous().to(dev)
+        part = torch.full((nb * int(L.llie_gram_part_floats(K, P)),), float("nan"), device=dev)
+        gtot = torch.full((nb, K * K + K), float("nan"), device=dev)
+        tick = torch.zeros(nb, dtype=torch.int32, device=dev)
+        for _ in range(2):  # the second launch runs on the tickets the first one left
+            N.check(L.llie_gram_stats(dtype, d0.data_ptr(), c0, d1.data_ptr() if c1 else None, c1, s_d.data_ptr(), b_d.data_ptr(), nb, P,
+                                      part.data_ptr(), gtot.data_ptr(), tick.data_ptr(), st), "gram_stats")
+        torch.cuda.synchronize()
+        assert int(tick.abs().sum()) == 0
+        return gtot.cpu()
+
+    got = run(slice(0, B))
+    assert torch.isfinite(got).all()
+    x = torch.cat([x0, x1], 2) if c1 else x0
+    a = (x.double() * sc[:, None, :].double() + bi[:, None, :].double()).clamp(0, 1).to(tdt).double()
+    G = torch.einsum("bpi,bpj->bij", a, a)
+    mref = a.sum(1)
+    ulp = 2.0 ** -10 if tdt == torch.float16 else 2.0 ** -7
+    # fp32 accumulation of exact products, plus the rare activation that rounds to T the other way on the device (fp32 FMA
+    # there, float64 here): one unit in the last place of one factor of one of P terms
+    gg = got[:, :K * K].view(B, K, K).double()
+    assert (gg - G).abs().max() <= 2e-5 * G.abs().max() + 4 * ulp, ((gg - G).abs().max().item(), G.abs().max().item())
+    assert torch.equal(gg, gg.transpose(1, 2))
+    mm = got[:, K * K:].double()
+    assert (mm - mref).abs().max() <= 2e-5 * mref.abs().max() + 4 * ulp
+    one = run(slice(B - 1, B))
+    assert torch.equal(one[0], got[B - 1])
+
+
+@pytest.mark.parametrize("cd,min_psnr", [("fp16", 50.0), ("bf16", 32.0)])
+def test_whole_network_with_gram_statistics_and_with_the_second_expand_pass(dev, cd, min_psnr):
+    """small@128: every recompute block (Cin 32 / 64 / 96) takes its norm2 statistics from the Gram matrix (knob "gram" = 1)
+    or from expand_stats (0): both against the fp32 CPU oracle by PSNR and against each other; sub-batches bit-identical."""
+    L = N.lib()
+    spec = oracle.make_spec("small", 128)
+    sd = oracle.synth_state_dict(oracle.param_shapes(spec))
+    m = M.LowLightDiffusion(unet_variant="small", image_size=128, num_inference_steps=4, compute_dtype=cd)
+    m.load_state_dict(sd)
+    m = m.to(dev).eval()
+    low = synth_input("r3:low128g", (3, 3, 128, 128), -1.0, -0.4)
+    noise = oracle.draw_noise(3, 128, 4, seed=22)
+    ref = oracle.enhance_ref(sd, spec, low, 4, noise)["enhanced"]
+    outs = {}
+    try:
+        for knob in (2, 0):  # 2: also below 32 768 pixels per image (every level of this 128 x 128 network)
+            N.check(L.llie_tune(b"gram", knob))
+            outs[knob] = m.enhance(low.to(dev), 4, noise=torch.stack(noise)).cpu()
+            assert _psnr01(outs[knob], ref) >= min_psnr, (knob, _psnr01(outs[knob], ref))
+        assert _psnr01(outs[2], outs[0]) >= min_psnr
+        N.check(L.llie_tune(b"gram", 2))
+        one = m.enhance(low[1:2].to(dev), 4, noise=torch.stack(noise)[:, 1:2]).cpu()
+        assert torch.equal(one[0], outs[2][1])
+        again = m.enhance(low.to(dev), 4, noise=torch.stack(noise)).cpu()
+        assert torch.equal(again, outs[2])
+    finally:
+        L.llie_tune(b"gram", 1)

@@ -36,7 +36,7 @@ def run(setting, steps=10):
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / steps
     for k in knobs:
-        N.check(L.llie_tune(k.encode(), {"irbx": 1, "irbx_dbuf": 0, "irbx_mask": 7, "irbx_tiles": 4, "gemm_bk128": 1024, "enhance_split": 2, "ztot": 1, "pwx": 1, "irbx_dwv": 1}.get(k, 0)))
+        N.check(L.llie_tune(k.encode(), {"irbx": 1, "irbx_dbuf": 0, "irbx_mask": 7, "irbx_tiles": 4, "gemm_bk128": 1024, "enhance_split": 2, "ztot": 1, "pwx": 1, "irbx_dwv": 1, "gram": 1}.get(k, 0)))
     return ms
 
 
