@@ -2203,6 +2203,59 @@ int llie_dwconv3x3(int dtype, const void* in, void* out, const float* scale, con
   return LLIE_OK;
 }
 
+// ---- the remaining kernel-level entry points of SURVEY.md 8b (GroupNorm finalize, dense 3x3, linear attention, SE MLP, FiLM)
+static int kerr(const char* what, hipError_t e) {
+  if (e == hipSuccess) return LLIE_OK;
+  if (e == hipErrorInvalidValue) { set_err("%s: shape outside the kernel contract", what); return LLIE_ERR_SHAPE; }
+  set_err("%s: %s", what, hipGetErrorString(e));
+  return (int)e;
+}
+int llie_groupnorm_finalize(const float* slab0, int ntiles0, int ch0, const float* slab1, int ntiles1, int ch1, int groups, int pixels,
+                            const float* gamma, const float* beta, const float* film, int64_t film_stride, float eps, float post_scale,
+                            int batch, float* scale_out, float* shift_out, llie_stream stream) {
+  if (!slab0 || !gamma || !beta || !scale_out || !shift_out || batch <= 0 || ch0 <= 0 || (slab1 && ch1 <= 0)) return LLIE_ERR_ARG;
+  GnFinalizeArgs a{};
+  a.src[0] = StatSrc{slab0, ntiles0, ch0};
+  if (slab1) a.src[1] = StatSrc{slab1, ntiles1, ch1};
+  a.C = ch0 + (slab1 ? ch1 : 0); a.groups = groups; a.P = pixels; a.gamma = gamma; a.beta = beta; a.film = film; a.film_stride = film_stride;
+  a.eps = eps; a.as = scale_out; a.ab = shift_out; a.B = batch; a.post_scale = post_scale;
+  return kerr("groupnorm_finalize", launch_gn_finalize(a, reinterpret_cast<hipStream_t>(stream)));
+}
+int llie_conv3x3(int dtype, int mode, const void* in, const void* w, const float* bias, void* out, float* stats, int batch, int Hi, int Wi,
+                 int Cin, int Cout, llie_stream stream) {
+  if (!in || !w || !out || dtype < 0 || dtype > 2 || (mode != 0 && mode != 1)) return LLIE_ERR_ARG;
+  Conv3Args a{};
+  a.in = in; a.w = w; a.bias = bias; a.out = out; a.stats = stats; a.B = batch; a.Hi = Hi; a.Wi = Wi; a.Cin = Cin; a.Cout = Cout; a.mode = mode;
+  return kerr("conv3x3", launch_conv3x3(dtype, a, reinterpret_cast<hipStream_t>(stream)));
+}
+int llie_conv3x3_tiles(int Ho, int Wo) { return conv3x3_ntiles(Ho, Wo); }
+int llie_linattn_splits(int N) { return linattn_nsplit(N); }
+int llie_linattn(int dtype, const void* qkv, float* kv_scratch, void* out, int batch, int N, int heads, llie_stream stream) {
+  if (!qkv || !kv_scratch || !out || dtype < 0 || dtype > 2 || batch <= 0 || N <= 0 || heads <= 0) return LLIE_ERR_ARG;
+  AttnArgs a{};
+  a.qkv = qkv; a.B = batch; a.N = N; a.heads = heads; a.kv = kv_scratch; a.out = out; a.nsplit = linattn_nsplit(N);
+  hipError_t e = launch_linattn_kv(dtype, a, reinterpret_cast<hipStream_t>(stream));
+  if (e == hipSuccess) e = launch_linattn_out(dtype, a, reinterpret_cast<hipStream_t>(stream));
+  return kerr("linattn", e);
+}
+int llie_se_mlp(int dtype, const float* pool_sums, int pixels, const void* w1, const float* b1, const void* w2, const float* b2, float* mean_scratch,
+                float* hidden_scratch, float* gate, int batch, int C, int Cs, llie_stream stream) {
+  if (!pool_sums || !w1 || !b1 || !w2 || !b2 || !mean_scratch || !hidden_scratch || !gate || dtype < 0 || dtype > 2 || batch <= 0 || C <= 0 || Cs <= 0)
+    return LLIE_ERR_ARG;
+  SeArgs a{};
+  a.pool = pool_sums; a.ntiles = 1; a.P = pixels; a.w1 = w1; a.b1 = b1; a.w2 = w2; a.b2 = b2; a.mean = mean_scratch; a.hid = hidden_scratch; a.gate = gate;
+  a.B = batch; a.C = C; a.Cs = Cs;
+  hipError_t e = launch_se_fc1(dtype, a, reinterpret_cast<hipStream_t>(stream));
+  if (e == hipSuccess) e = launch_se_fc2(dtype, a, reinterpret_cast<hipStream_t>(stream));
+  return kerr("se_mlp", e);
+}
+int llie_film(const float* silu_temb, const float* wf, const float* bf, float* film, int rows, int T, int F, llie_stream stream) {
+  if (!silu_temb || !wf || !bf || !film || rows <= 0 || T <= 0 || F <= 0) return LLIE_ERR_ARG;
+  FilmArgs a{};
+  a.silu_temb = silu_temb; a.rows = rows; a.T = T; a.wf = wf; a.bf = bf; a.film = film; a.F = F;
+  return kerr("film", launch_film(a, reinterpret_cast<hipStream_t>(stream)));
+}
+
 int llie_preprocess_u8(const uint8_t* img, int batch, int H0, int W0, float* out, int S, llie_stream stream) {
   if (!img || !out) return LLIE_ERR_ARG;
   hipError_t e = launch_preprocess_u8(img, batch, H0, W0, out, S, reinterpret_cast<hipStream_t>(stream));

@@ -221,6 +221,33 @@ int llie_pw_gemm_tile_rows(int P);
  *   from an earlier call with the same weights -- the GEMM alone).  stats: as llie_pw_gemm. */
 int llie_pw_expand(int dtype, const llie_gemm_seg* segs, int nseg, const float* w32, void* wpack, void* out, float* stats,
                    int M, int N, int P, llie_stream stream);
+/* The remaining per-kernel entry points of the hot path.  All tensors are device pointers; activations are NHWC of
+ * the compute type `dtype` (0 fp32, 1 fp16, 2 bf16), tables and statistics fp32.
+ *
+ * llie_groupnorm_finalize: nn.GroupNorm(groups, C) statistics (efficient_unet.py:170-171,263,268,528) from per-tile
+ *   (sum, sum of squares) slabs [batch][ntiles][2][ch] of up to two channel segments (a virtual concat) to the per-(image,
+ *   channel) affine `scale`, `shift` [batch][C] that consumers apply on load; `film` (or NULL): [rows][2 C] FiLM (1 + scale, shift
+ *   folded in, :215-217) with row stride film_stride (0 = one row for all images); post_scale 0 = none.
+ * llie_conv3x3: Downsample (:367, mode 0: stride 2, pad 1) / Upsample (:383-384, mode 1: bilinear x2 then 3x3 pad 1) as implicit
+ *   GEMM; w [9][Cout][Cin] of the compute type (tap-major), stats (or NULL) [batch][llie_conv3x3_tiles(Ho, Wo)][2][Cout].
+ * llie_linattn: LinearAttention core (:288-302) on qkv [batch][N][3 * 32 heads] (q | k | v, head-major channels, dim_head 32):
+ *   phi = elu + 1 on q and k, kv = sum_n phi(k) v^T, out = phi(q) kv / (phi(q) . sum_n phi(k) + 1e-6) -> [batch][N][32 heads];
+ *   kv_scratch: llie_linattn_splits(N) * batch * heads * 32 * 33 floats.
+ * llie_se_mlp: SqueezeExcitation MLP (:96-100): gate = sigmoid(W2 relu6(W1 mean + b1) + b2), mean = pool_sums / pixels;
+ *   w1 [Cs][C], w2 [C][Cs] of the compute type; scratch: mean [batch][C], hidden [batch][Cs]; gate out [batch][C].
+ * llie_film: all FiLM projections of a network in one launch (:189-192,215): film[r][f] = bf[f] + Wf[f][:] . silu_temb[r][:]. */
+int llie_groupnorm_finalize(const float* slab0, int ntiles0, int ch0, const float* slab1, int ntiles1, int ch1, int groups, int pixels,
+                            const float* gamma, const float* beta, const float* film, int64_t film_stride, float eps, float post_scale,
+                            int batch, float* scale_out, float* shift_out, llie_stream stream);
+int llie_conv3x3(int dtype, int mode, const void* in, const void* w, const float* bias, void* out, float* stats, int batch, int Hi, int Wi,
+                 int Cin, int Cout, llie_stream stream);
+int llie_conv3x3_tiles(int Ho, int Wo);
+int llie_linattn(int dtype, const void* qkv, float* kv_scratch, void* out, int batch, int N, int heads, llie_stream stream);
+int llie_linattn_splits(int N);
+int llie_se_mlp(int dtype, const float* pool_sums, int pixels, const void* w1, const float* b1, const void* w2, const float* b2, float* mean_scratch,
+                float* hidden_scratch, float* gate, int batch, int C, int Cs, llie_stream stream);
+int llie_film(const float* silu_temb, const float* wf, const float* bf, float* film, int rows, int T, int F, llie_stream stream);
+
 /* Statistics pass of the recompute form of InvertedResidualBlock (efficient_unet.py:207-212) on its own: Gram matrix
  * G = sum_px a' a'^T and column sums m = sum_px a' of a' = clamp01(x * scale + bias) rounded to the compute type, per image
  * (gram.hip).  x0 / x1: NHWC [batch][pixels][c0 / c1] of the compute type (x1 may be NULL with c1 = 0), c0 + c1 in {32, 64, 96},

@@ -255,3 +255,124 @@ def test_whole_network_with_gram_statistics_and_with_the_second_expand_pass(dev,
         assert torch.equal(again, outs[2])
     finally:
         L.llie_tune(b"gram", 1)
+
+
+# ------------------------------------------------------------------ the remaining per-kernel entry points
+def _nhwc(x, tdt):  # [B][C][H][W] fp32 -> [B][H*W][C] T
+    b, c, h, w = x.shape
+    return x.permute(0, 2, 3, 1).reshape(b, h * w, c).contiguous().to(tdt)
+
+
+@pytest.mark.parametrize("c0,c1,P,film", [(32, 0, 4096, False), (64, 32, 1024, True), (256, 0, 256, True)])
+def test_groupnorm_finalize_entry_point_vs_torch(dev, c0, c1, P, film):
+    """llie_groupnorm_finalize: slabs of per-tile (sum, sum of squares) -> the affine a consumer applies on load; against
+    F.group_norm (efficient_unet.py:170-171) with FiLM folded in (:215-217), over a virtual concat of two tensors."""
+    L = N.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    B, C, groups = 3, c0 + c1, 32
+    g = torch.Generator().manual_seed(C + P)
+    y = torch.randn(B, P, C, generator=g) * 1.7 + 0.3
+    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.2
+    fl = torch.randn(B, 2 * C, generator=g) * 0.3
+    nt = P // 128
+    def slab(t):
+        t = t.view(B, nt, 128, t.shape[-1]).double()
+        return torch.stack([t.sum(2), (t * t).sum(2)], 2).float().contiguous().to(dev)
+    s0 = slab(y[..., :c0].contiguous())
+    s1 = slab(y[..., c0:].contiguous()) if c1 else None
+    sc, sh = torch.empty(B, C, device=dev), torch.empty(B, C, device=dev)
+    gd, bd, fd = gamma.to(dev), beta.to(dev), fl.to(dev)
+    N.check(L.llie_groupnorm_finalize(s0.data_ptr(), nt, c0, s1.data_ptr() if c1 else None, nt if c1 else 0, c1, groups, P, gd.data_ptr(), bd.data_ptr(),
+                                      fd.data_ptr() if film else None, 2 * C if film else 0, 1e-5, 0.0, B, sc.data_ptr(), sh.data_ptr(), st), "gn_finalize")
+    torch.cuda.synchronize()
+    got = y * sc.cpu()[:, None, :] + sh.cpu()[:, None, :]
+    ref = torch.nn.functional.group_norm(y.permute(0, 2, 1).double(), groups, gamma.double(), beta.double(), 1e-5).permute(0, 2, 1)
+    if film:
+        ref = ref * (1 + fl[:, None, :C].double()) + fl[:, None, C:].double()
+    assert (got.double() - ref).abs().max() < 2e-5
+
+
+@pytest.mark.parametrize("dtype,tdt,tol", [(0, torch.float32, 2e-5), (1, torch.float16, 4e-3), (2, torch.bfloat16, 3e-2)])
+@pytest.mark.parametrize("mode,cin,cout,hw", [(0, 32, 64, 32), (1, 64, 64, 16), (1, 128, 128, 8)])
+def test_conv3x3_entry_point_vs_torch(dev, dtype, tdt, tol, mode, cin, cout, hw):
+    """llie_conv3x3 against F.conv2d: Downsample (efficient_unet.py:367) and Upsample (:383-384, bilinear x2 first)."""
+    L = N.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    B = 2
+    g = torch.Generator().manual_seed(cin + hw + mode)
+    x = torch.randn(B, cin, hw, hw, generator=g)
+    w = torch.randn(cout, cin, 3, 3, generator=g) / math.sqrt(9 * cin)
+    b = torch.randn(cout, generator=g) * 0.1
+    xd = _nhwc(x, tdt).to(dev)
+    wd = w.permute(2, 3, 0, 1).reshape(9, cout, cin).contiguous().to(tdt).to(dev)
+    bd = b.to(dev)
+    ho = hw // 2 if mode == 0 else hw * 2
+    out = torch.full((B, ho * ho, cout), float("nan"), dtype=tdt, device=dev)
+    nt = int(L.llie_conv3x3_tiles(ho, ho))
+    stats = torch.full((B, nt, 2, cout), float("nan"), device=dev)
+    N.check(L.llie_conv3x3(dtype, mode, xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), out.data_ptr(), stats.data_ptr(), B, hw, hw, cin, cout, st), "conv3x3")
+    torch.cuda.synchronize()
+    xr, wr = xd.cpu().float().view(B, hw, hw, cin).permute(0, 3, 1, 2), wd.cpu().float().view(3, 3, cout, cin).permute(2, 3, 0, 1)
+    if mode == 0:
+        ref = torch.nn.functional.conv2d(xr.double(), wr.double(), b.double(), stride=2, padding=1)
+    else:
+        up = torch.nn.functional.interpolate(xr.double(), scale_factor=2, mode="bilinear", align_corners=False)
+        ref = torch.nn.functional.conv2d(up, wr.double(), b.double(), padding=1)
+    got = out.cpu().double().view(B, ho, ho, cout).permute(0, 3, 1, 2)
+    assert (got - ref).abs().max() < tol * max(1.0, ref.abs().max().item()), (got - ref).abs().max().item()
+    o = out.cpu().double()
+    assert torch.allclose(stats.cpu().double().sum(1)[:, 0], o.sum(1), rtol=1e-4, atol=1e-2)
+    assert torch.allclose(stats.cpu().double().sum(1)[:, 1], (o * o).sum(1), rtol=1e-4, atol=1e-2)
+
+
+@pytest.mark.parametrize("dtype,tdt,tol", [(0, torch.float32, 2e-5), (1, torch.float16, 4e-3), (2, torch.bfloat16, 3e-2)])
+def test_linattn_entry_point_vs_torch(dev, dtype, tdt, tol):
+    """llie_linattn against the restatement of LinearAttention's core (efficient_unet.py:288-302; phi = elu + 1, no scale)."""
+    L = N.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    B, n, heads = 2, 1024, 4
+    inner = heads * 32
+    g = torch.Generator().manual_seed(7)
+    qkv = (torch.randn(B, n, 3 * inner, generator=g) * 0.8).to(tdt)
+    qd = qkv.to(dev)
+    kv = torch.empty(int(L.llie_linattn_splits(n)) * B * heads * 32 * 33, device=dev)
+    out = torch.full((B, n, inner), float("nan"), dtype=tdt, device=dev)
+    N.check(L.llie_linattn(dtype, qd.data_ptr(), kv.data_ptr(), out.data_ptr(), B, n, heads, st), "linattn")
+    torch.cuda.synchronize()
+    q, k, v = (z.double().view(B, n, heads, 32).permute(0, 2, 3, 1) for z in qkv.split(inner, dim=2))  # [b][h][d][n]
+    q, k = torch.nn.functional.elu(q) + 1, torch.nn.functional.elu(k) + 1
+    kvr = torch.einsum("bhdn,bhen->bhde", k, v)
+    num = torch.einsum("bhdn,bhde->bhen", q, kvr)
+    den = torch.einsum("bhdn,bhd->bhn", q, k.sum(-1))[:, :, None, :] + 1e-6
+    ref = (num / den).permute(0, 3, 1, 2).reshape(B, n, inner)
+    assert (out.cpu().double() - ref).abs().max() < tol * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("dtype,tdt,tol", [(0, torch.float32, 1e-5), (1, torch.float16, 2e-3), (2, torch.bfloat16, 1.5e-2)])
+def test_se_mlp_and_film_entry_points_vs_torch(dev, dtype, tdt, tol):
+    """llie_se_mlp (SqueezeExcitation, efficient_unet.py:96-100) and llie_film (:189-192) against plain PyTorch."""
+    L = N.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    B, C, Cs, P = 5, 512, 128, 4096
+    g = torch.Generator().manual_seed(11)
+    sums = torch.randn(B, C, generator=g) * P * 0.3
+    w1 = (torch.randn(Cs, C, generator=g) / math.sqrt(C)).to(tdt)
+    w2 = (torch.randn(C, Cs, generator=g) / math.sqrt(Cs)).to(tdt)
+    b1, b2 = torch.randn(Cs, generator=g) * 0.1, torch.randn(C, generator=g) * 0.1
+    d = [t.to(dev) for t in (sums, w1, b1, w2, b2)]
+    mean, hid, gate = torch.empty(B, C, device=dev), torch.empty(B, Cs, device=dev), torch.full((B, C), float("nan"), device=dev)
+    N.check(L.llie_se_mlp(dtype, d[0].data_ptr(), P, d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(), d[4].data_ptr(), mean.data_ptr(), hid.data_ptr(),
+                          gate.data_ptr(), B, C, Cs, st), "se_mlp")
+    m = sums.double() / P
+    h = torch.nn.functional.relu6(m @ w1.double().t() + b1.double())
+    ref = torch.sigmoid(h @ w2.double().t() + b2.double())
+    torch.cuda.synchronize()
+    assert (gate.cpu().double() - ref).abs().max() < tol
+    rows, T, F_ = 3, 128, 1000
+    stemb = torch.randn(rows, T, generator=g)
+    wf, bf = torch.randn(F_, T, generator=g) / math.sqrt(T), torch.randn(F_, generator=g) * 0.1
+    film = torch.full((rows, F_), float("nan"), device=dev)
+    dd = [t.to(dev) for t in (stemb, wf, bf)]
+    N.check(L.llie_film(dd[0].data_ptr(), dd[1].data_ptr(), dd[2].data_ptr(), film.data_ptr(), rows, T, F_, st), "film")
+    torch.cuda.synchronize()
+    assert (film.cpu().double() - (stemb.double() @ wf.double().t() + bf.double())).abs().max() < 2e-5
