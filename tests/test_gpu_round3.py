@@ -3,6 +3,11 @@
   * the activation-stationary expand GEMM (pwx.hip, llie_pw_expand) against a plain PyTorch fp32 restatement of the same
     operator (efficient_unet.py:207-208 norm1 + ReLU6 prologue, :174 expand, the statistics norm2 :212 needs), against the
     tile kernel it replaces (llie_pw_gemm), bitwise batch invariance, and through the whole network (knob "pwx")
+  * a batch equals its halves bit for bit whatever the launch-size heuristics choose (fp32 / fp16 / bf16, both expand paths)
+  * GroupNorm-2 statistics of the recompute form from the Gram matrix of the block input (gram.hip, llie_gram_stats) against a
+    float64 restatement, and through the whole network with the knob on and off
+  * the remaining per-kernel entry points of SURVEY.md 8b (llie_groupnorm_finalize, llie_conv3x3, llie_linattn, llie_se_mlp,
+    llie_film) against plain PyTorch
 """
 import importlib
 import math
