@@ -2320,6 +2320,7 @@ int llie_tune(const char* knob, int value) {
   if (!strcmp(knob, "irbx_mask")) { g_irbx_mask = value; return LLIE_OK; }
   if (!strcmp(knob, "irbx_ablate")) { irbx_ablate(value); return LLIE_OK; }
   if (!strcmp(knob, "irbx_dwv")) { irbx_dwv(value); return LLIE_OK; }
+  if (!strcmp(knob, "irbx_grid")) { irbx_grid(value); return LLIE_OK; }
   if (!strcmp(knob, "gemm_stamp")) { pw_gemm_stamp(value); return LLIE_OK; }
   if (!strcmp(knob, "pwx")) { pw_expand_enable(value); return LLIE_OK; }
   if (!strcmp(knob, "pwx_ablate")) { pw_expand_debug(value, -1); return LLIE_OK; }
@@ -2348,10 +2349,10 @@ int llie_debug_pwx_stamps(double* out4) {
 }
 
 // diagnostic: mean per-wave cycles of the last stamped expand_dw launch (llie_tune("irbx_stamp", 1)); synchronises
-int llie_debug_irbx_stamps(double* out4) {
-  if (!out4) return LLIE_ERR_ARG;
+int llie_debug_irbx_stamps(double* out10) {
+  if (!out10) return LLIE_ERR_ARG;
   hipError_t e = hipDeviceSynchronize();
-  if (e == hipSuccess) e = irbx_stamp_fetch(out4);
+  if (e == hipSuccess) e = irbx_stamp_fetch(out10);
   return e == hipSuccess ? LLIE_OK : LLIE_ERR_ARG;
 }
 

@@ -166,11 +166,16 @@ constexpr int kXNPB = 6;
 // fixed 16-byte channel slot (the expand epilogue's ds_write_b128, the depthwise MFMAs' ds_read_b128): the 144-byte
 // pitch (36 dwords) spreads consecutive pixels over distinct bank groups for either instruction's lane grouping.
 constexpr int SHP = 144;
+constexpr int kXStamps = 9;
 
 // STAMP = diagnostic build (llie_tune("irbx_stamp", 1)): s_memtime around the phases, summed per wave into a.dbg
-// ([workgroup][wave][4] = {tile prologue, MFMA phase, barrier wait, depthwise phase} cycles); never used in production.
+// ([workgroup][wave][kXStamps] cycles: 0 wait for the prefetched / loaded x tile (vmcnt), 1 activate + ds_write of the x tile,
+// 2 next tile's loads issued + halo validity, 3 tile-top barrier, 4 pool flush behind it, 5 chunk-top barrier + flush
+// (chunks after the first), 6 expand MFMAs + epilogue + ds_write, 7 barrier behind them, 8 depthwise phase incl. the h2
+// stores and the pool partial); never used in production.
 // ABL (diagnostic builds only): timing ablations -- 1 no h2 stores, 2 no pool sums, 4 h2 stores confined to L2, 8 no depthwise MFMAs,
-// 16 h2 stores as contiguous kilobytes (wrong layout, same bytes).
+// 16 h2 stores as contiguous kilobytes (wrong layout, same bytes), 32 no workgroup barriers inside the tile loop (what a
+// barrier-free structure could gain at most; results wrong).
 // DWV = form of the depthwise phase: 0 = one tap per 32x32x16 MFMA (k = 16 channels of a diagonal weight matrix),
 // 1 = two taps per 16x16x32 MFMA (k = 2 taps x 16 channels): the same ds_read_b128 data operand per MFMA, half the
 // matrix-pipe time per MFMA -> 640 instead of 1 152 pipe cycles per 64-channel chunk and wave.
@@ -250,9 +255,11 @@ __global__ void __launch_bounds__(256, (KS == 2 && !DBUF) ? 3 : 2) expand_dw_ker
     dq[blk] = drow[blk] * kXH_W + (n & 15);
   }
 
-  const int tile_first = blockIdx.x * tiles_per_wg;
   const int ntiles_img = tiles_x * (a.H / kXT_H);
-  const int tile_last = tile_first + tiles_per_wg < ntiles_img ? tile_first + tiles_per_wg : ntiles_img;
+  // tiles_per_wg > 0: fixed runs; <= 0: the image's tiles split evenly over the gridDim.x workgroups (knob "irbx_grid")
+  const int tile_first = tiles_per_wg > 0 ? blockIdx.x * tiles_per_wg : (int)((long)blockIdx.x * ntiles_img / gridDim.x);
+  const int tile_end = tiles_per_wg > 0 ? tile_first + tiles_per_wg : (int)((long)(blockIdx.x + 1) * ntiles_img / gridDim.x);
+  const int tile_last = tile_end < ntiles_img ? tile_end : ntiles_img;
 
   // x halo tile: vector v = tid + j*256 -> pixel v / (2 KS), channel vector v % (2 KS)
   vec_t raw[XPT];
@@ -282,13 +289,18 @@ __global__ void __launch_bounds__(256, (KS == 2 && !DBUF) ? 3 : 2) expand_dw_ker
   load_wf(chunk0);
   wg_barrier();  // constants staged
 
-  unsigned long long tk[4] = {0, 0, 0, 0}, t_prev = 0;
+  unsigned long long tk[kXStamps] = {}, t_prev = 0;
   auto stamp = [&](int slot) {
     if constexpr (STAMP) {
+      __builtin_amdgcn_sched_barrier(0);
       const unsigned long long now = __builtin_amdgcn_s_memtime();
+      __builtin_amdgcn_sched_barrier(0);
       if (slot >= 0) tk[slot] += now - t_prev;
       t_prev = now;
     }
+  };
+  auto tile_barrier = [&]() {  // the barriers inside the tile loop (ABL 32 removes them: timing only)
+    if constexpr (!(ABL & 32)) wg_barrier();
   };
   stamp(-1);
   const bool has_pool = a.pool != nullptr || a.pool_tot != nullptr;
@@ -334,6 +346,7 @@ __global__ void __launch_bounds__(256, (KS == 2 && !DBUF) ? 3 : 2) expand_dw_ker
     // pending, and the wait for the prefetched weight slices at its head becomes vmcnt(4 + ...) -- the depthwise phase's four
     // h2 stores stay in flight -- instead of the vmcnt(0) that the merge with this path forced.
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+    stamp(0);
 #pragma unroll
     for (int j = 0; j < XPT; ++j) {
       const int v = tid + j * 256;
@@ -342,6 +355,7 @@ __global__ void __launch_bounds__(256, (KS == 2 && !DBUF) ? 3 : 2) expand_dw_ker
         *reinterpret_cast<vec_t*>(sX + q * XP + k * 2) = activate8<T>(raw[j], aff1 + k, aff1 + K + k);
       }
     }
+    stamp(1);
     if (PREF && tile + 1 < tile_last) load_tile(tile + 1);
     // validity of this lane's three halo pixels (zero padding of the depthwise input)
     const bool border = ty == 0 || tx == 0 || ty == a.H / kXT_H - 1 || tx == tiles_x - 1;
@@ -352,9 +366,11 @@ __global__ void __launch_bounds__(256, (KS == 2 && !DBUF) ? 3 : 2) expand_dw_ker
       const int gy = y0 - 1 + q / kXH_W, gx = x0p - 1 + q % kXH_W;
       ok[i] = q < kXNPX && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
     }
-    wg_barrier();
+    stamp(2);
+    tile_barrier();
+    stamp(3);
     if (!DBUF) flush_pool();
-    stamp(0);
+    stamp(4);
 
     // (Unrolling this loop lets hipcc count the memory operations between a prefetch and its use -- vmcnt(5) instead of
     // vmcnt(2) for the weight slices -- but costs 11 spilled registers, and every spill reload waits vmcnt(0), i.e. for the
@@ -362,8 +378,9 @@ __global__ void __launch_bounds__(256, (KS == 2 && !DBUF) ? 3 : 2) expand_dw_ker
     for (int chunk = chunk0; chunk < chunk1; ++chunk) {
       unsigned char* buf = sH + (DBUF ? par * SH_BYTES : 0);
       if (!DBUF && chunk > chunk0) {
-        wg_barrier();  // previous depthwise phase done with sH
+        tile_barrier();  // previous depthwise phase done with sH
         flush_pool();
+        stamp(5);
       }
       // ---- MFMA: h1^T block (32 channels x 32 pixels) x 3 pixel blocks
       const int ch0 = chunk * 64 + chb * 32;
@@ -426,10 +443,10 @@ __global__ void __launch_bounds__(256, (KS == 2 && !DBUF) ? 3 : 2) expand_dw_ker
         *reinterpret_cast<u32x4*>(buf + q * SHP + (chb * 4 + 2 * h) * 16) = lo;
         *reinterpret_cast<u32x4*>(buf + q * SHP + (chb * 4 + 2 * h + 1) * 16) = hi2;
       }
-      stamp(1);
-      wg_barrier();
+      stamp(6);
+      tile_barrier();
       if (DBUF) flush_pool();
-      stamp(2);
+      stamp(7);
       // ---- depthwise 3x3 on the MFMA pipe.  The VALU is what this kernel runs out of (a wave64 instruction costs a SIMD
       // 4 cycles; 72 FMAs per 16 output bytes), the matrix pipe idles.  A depthwise tap is a diagonal matrix:
       //   out[ch][px] += sum_k diag(w_tap)[ch][k] * in[k][px + tap]      (k over the block's channels, 16 per MFMA)
@@ -669,14 +686,14 @@ __global__ void __launch_bounds__(256, (KS == 2 && !DBUF) ? 3 : 2) expand_dw_ker
         }
       }
       if (DBUF) par ^= 1;
-      stamp(3);
+      stamp(8);
     }
   }
   if constexpr (STAMP) {
     if (a.dbg && lane == 0) {
       const size_t wg = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) a.dbg[(wg * 4 + wave) * 4 + i] = tk[i];
+      for (int i = 0; i < kXStamps; ++i) a.dbg[(wg * 4 + wave) * kXStamps + i] = tk[i];
     }
   }
   if (has_pool) {
@@ -706,21 +723,23 @@ int irbx_stats_rows(int P) {
   return rp;
 }
 
-static int g_irbx_dbuf = 0, g_irbx_tiles = 4, g_irbx_stamp = 0, g_irbx_ablate = 0, g_irbx_dwv = 1;
+static int g_irbx_dbuf = 0, g_irbx_tiles = 4, g_irbx_stamp = 0, g_irbx_ablate = 0, g_irbx_dwv = 1, g_irbx_grid = 0;
+void irbx_grid(int v) { g_irbx_grid = v; }
 void irbx_dwv(int v) { g_irbx_dwv = v; }
 void irbx_ablate(int v) { g_irbx_ablate = v; }
 static unsigned long long* g_irbx_dbg = nullptr;
 static size_t g_irbx_dbg_n = 0;  // entries of the last stamped launch
 void irbx_stamp(int v) { g_irbx_stamp = v; }
-// mean cycles per wave of the last stamped launch: out[4] = {tile prologue, MFMA phase, barrier wait, depthwise phase}
+// mean cycles per wave of the last stamped launch: out[0 .. kXStamps) = the slots listed at STAMP, out[kXStamps] = waves averaged
 hipError_t irbx_stamp_fetch(double* out) {
   if (!g_irbx_dbg || !g_irbx_dbg_n) return hipErrorInvalidValue;
   std::vector<unsigned long long> h(g_irbx_dbg_n);
   hipError_t e = hipMemcpy(h.data(), g_irbx_dbg, g_irbx_dbg_n * 8, hipMemcpyDeviceToHost);
   if (e != hipSuccess) return e;
-  for (int i = 0; i < 4; ++i) out[i] = 0.0;
-  for (size_t i = 0; i < g_irbx_dbg_n; ++i) out[i & 3] += (double)h[i];
-  for (int i = 0; i < 4; ++i) out[i] /= (double)(g_irbx_dbg_n / 4);
+  for (int i = 0; i < kXStamps; ++i) out[i] = 0.0;
+  for (size_t i = 0; i < g_irbx_dbg_n; ++i) out[i % kXStamps] += (double)h[i];
+  for (int i = 0; i < kXStamps; ++i) out[i] /= (double)(g_irbx_dbg_n / kXStamps);
+  out[kXStamps] = (double)(g_irbx_dbg_n / kXStamps);
   return hipSuccess;
 }
 void irbx_tune(int dbuf, int tiles_per_wg) {
@@ -768,33 +787,46 @@ static hipError_t launch_dw_cfg(const IrbxArgs& a, hipStream_t s) {
   static const std::string name = std::string("expand_dw_kernel<") + TypeName<T>::value + ", " + std::to_string(KS) + ", " +
                                   (DBUF ? "1" : "0") + ">";
   note_kernel(name.c_str());
-  const dim3 grid(ntiles / tpw, nchunks / cpw, a.B);
-  if constexpr (KS == 2 && std::is_same<T, half_t>::value) {
-    if (g_irbx_stamp) {  // diagnostic build with in-kernel cycle stamps
-      const size_t n = (size_t)grid.x * grid.y * grid.z * 16;
-      if (n > g_irbx_dbg_n || !g_irbx_dbg) {
-        if (g_irbx_dbg) (void)hipFree(g_irbx_dbg);
-        hipError_t e = hipMalloc(reinterpret_cast<void**>(&g_irbx_dbg), n * 8);
-        if (e != hipSuccess) return e;
-      }
-      g_irbx_dbg_n = n;
+  dim3 grid(ntiles / tpw, nchunks / cpw, a.B);
+  if (g_irbx_grid > 0) {  // knob "irbx_grid": about this many workgroups per launch, each image's tiles split evenly over its share
+    int gx = g_irbx_grid / (a.B * (nchunks / cpw));
+    gx = gx < 1 ? 1 : (gx > ntiles ? ntiles : gx);
+    grid.x = gx;
+    tpw = 0;
+  }
+  if constexpr (std::is_same<T, half_t>::value && !DBUF) {
+    if (g_irbx_stamp || a.ablate) {  // diagnostic builds: in-kernel cycle stamps and / or timing ablations (fp16 only)
       IrbxArgs b = a;
-      b.dbg = g_irbx_dbg;
+      if (g_irbx_stamp) {
+        const size_t n = (size_t)grid.x * grid.y * grid.z * 4 * kXStamps;
+        if (n > g_irbx_dbg_n || !g_irbx_dbg) {
+          if (g_irbx_dbg) (void)hipFree(g_irbx_dbg);
+          hipError_t e = hipMalloc(reinterpret_cast<void**>(&g_irbx_dbg), n * 8);
+          if (e != hipSuccess) return e;
+        }
+        g_irbx_dbg_n = n;
+        b.dbg = g_irbx_dbg;
+      }
       auto go = [&](auto kern) -> hipError_t {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, b, tpw, cpw);
         return hipGetLastError();
       };
-      switch (a.ablate) {
-        case 0: return go(&expand_dw_kernel<T, KS, DBUF, true, 0>);
-        case 1: return go(&expand_dw_kernel<T, KS, DBUF, true, 1>);
-        case 2: return go(&expand_dw_kernel<T, KS, DBUF, true, 2>);
-        case 3: return go(&expand_dw_kernel<T, KS, DBUF, true, 3>);
-        case 4: return go(&expand_dw_kernel<T, KS, DBUF, true, 4>);
-        case 16: return go(&expand_dw_kernel<T, KS, DBUF, true, 16>);
-        case 8: return go(&expand_dw_kernel<T, KS, DBUF, true, 8>);
-        case 11: return go(&expand_dw_kernel<T, KS, DBUF, true, 11>);
+      if (g_irbx_stamp) {
+        switch (a.ablate) {
+          case 0: return go(&expand_dw_kernel<T, KS, DBUF, true, 0>);
+          case 1: return go(&expand_dw_kernel<T, KS, DBUF, true, 1>);
+          case 32: return go(&expand_dw_kernel<T, KS, DBUF, true, 32>);
+        }
+      } else {
+        switch (a.ablate) {
+          case 1: return go(&expand_dw_kernel<T, KS, DBUF, false, 1>);
+          case 4: return go(&expand_dw_kernel<T, KS, DBUF, false, 4>);
+          case 8: return go(&expand_dw_kernel<T, KS, DBUF, false, 8>);
+          case 32: return go(&expand_dw_kernel<T, KS, DBUF, false, 32>);
+          case 33: return go(&expand_dw_kernel<T, KS, DBUF, false, 33>);
+        }
       }
       return hipErrorInvalidValue;
     }

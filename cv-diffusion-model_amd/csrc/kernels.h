@@ -167,33 +167,12 @@ struct IrbxArgs {
   int B, H, W, Chid;
   unsigned long long* dbg;                       // diagnostic builds only (irbx_stamp)
   int ablate;                                    // timing ablations (results wrong when non-zero; 0 in production)
-  // expand_dw output mode (identity-residual blocks with 32 output channels, irbx_project_supported):
-  //   0  h2 = depthwise output to `out` (+ SE pool sums)                       -- the project GEMM follows as its own launch
-  //   1  SE pool sums only: h2 is NOT stored (first pass of the fully fused form)
-  //   2  second pass: the depthwise weights carry the SE gate, h2 stays in registers and is contracted with the project
-  //      weights on the spot: y = W3 (gate * h2) + x  -> `yout` (NHWC T) with its statistics slab `ystats`
-  //      (efficient_unet.py:221-236: se, project, identity residual)
-  int mode;
-  const float* gate;                             // mode 2: [B][Chid] SE gates
-  const void* w3p;                               // mode 2: project weights [Cout][Chid] packed by launch_pack_project
-  void* yout; float* ystats; int Cout;           // mode 2 outputs; ystats = [B][P / 128][2][Cout]
 };
-// project weights for the fused second pass: T, MFMA 16x16x32 A-fragment order with the channel order of the depthwise epilogue
-//   dst[((kstep * (Cout / 16) + ct) * 64 + lane) * 8 + j] = W[16 ct + (lane & 15)][32 kstep + choff(lane >> 4) + j],
-//   choff(g) = 8 (g >> 1) + 16 (g & 1)
-__host__ __device__ inline long long irbx_project_pack_index(int n, int k, int Cout) {
-  const int kk = k & 31, q = kk >> 3;                   // q = channel octet inside the 32-channel block
-  const int g = ((q & 1) << 1) | (q >> 1);              // octets 0, 1, 2, 3 live in lane groups 0, 2, 1, 3
-  const int lane = (n & 15) + 16 * g;
-  return ((((long long)(k >> 5) * (Cout >> 4) + (n >> 4)) * 64 + lane) << 3) + (kk & 7);
-}
-hipError_t launch_pack_project(int dtype, const float* src, void* dst, int Cout, int Chid, int ld, hipStream_t s);
-bool irbx_project_supported(int dtype, int Cin, int Cout, int Chid, int H, int W);
-void irbx_project_enable(int v);  // knob "irbx_proj"
 void irbx_ablate(int v);
+void irbx_grid(int v);   // knob "irbx_grid": workgroups per expand_dw launch (0 = heuristics); each image's tiles are split evenly
 void irbx_dwv(int v);  // depthwise phase of expand_dw: 1 = two taps per 16x16x32 MFMA (default), 0 = one tap per 32x32x16 MFMA
 void irbx_stamp(int v);
-hipError_t irbx_stamp_fetch(double* out4);
+hipError_t irbx_stamp_fetch(double* out10);  // 9 slots (irbx.hip: STAMP) + the number of waves averaged
 bool irbx_supported(int dtype, int Cin, int c0, int Chid, int H, int W);
 int irbx_pool_tiles(int H, int W);
 int irbx_stats_rows(int P);

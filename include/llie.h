@@ -282,7 +282,7 @@ int llie_rw_probe(const void* src, void* dst, int64_t units, int reads, int writ
  * Threading: the knobs are plain process-wide variables read by every forward; call llie_tune only while no other
  * thread is inside an llie_* compute call (same rule as the handle itself: SURVEY.md 8b, one stream at a time). */
 int llie_tune(const char* knob, int value);
-int llie_debug_irbx_stamps(double* out4); /* diagnostic builds: see irbx.hip (STAMP) */
+int llie_debug_irbx_stamps(double* out10); /* diagnostic builds: 9 per-wave cycle sums of expand_dw (irbx.hip: STAMP) + waves averaged */
 int llie_debug_gemm_stamps(double* out3); /* diagnostic builds: see gemm.hip (STAMP) */
 int llie_debug_pwx_stamps(double* out4);  /* diagnostic builds: see pwx.hip (STAMP): {A phase, channel loop, of which waiting for the weight DMA} cycles per wave, waves */
 

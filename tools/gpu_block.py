@@ -40,11 +40,13 @@ def main():
     print(f"irb {cin}->{cout} {hw}x{hw} B={b} irbx={irbx} dbuf={dbuf} ablate={ablate}: {(time.perf_counter() - t0) / reps * 1e3:.3f} ms per block "
           f"(incl. NCHW<->NHWC conversion of the operator boundary)")
     if stamp:
-        out = (C.c_double * 4)()
+        out = (C.c_double * 10)()
         N.check(L.llie_debug_irbx_stamps(out))
-        tot = sum(out)
-        print("expand_dw mean cycles per wave (s_memtime, 100 MHz ticks x ...): "
-              + ", ".join(f"{n} {v:.0f} ({100 * v / tot:.0f}%)" for n, v in zip(["tile prologue", "MFMA phase", "barrier wait", "depthwise phase"], out)))
+        names = ["x wait (vmcnt)", "activate + ds_write", "next-tile loads + halo flags", "tile-top barrier", "pool flush", "chunk-top barrier + flush",
+                 "expand MFMAs + epilogue", "barrier behind them", "depthwise phase + stores"]
+        tot = sum(out[:9])
+        print(f"expand_dw mean shader cycles per wave over {out[9]:.0f} waves (s_memtime): total {tot:.0f}\n  "
+              + "\n  ".join(f"{n:30s} {v:9.0f} ({100 * v / tot:4.1f}%)" for n, v in zip(names, out)))
 
 
 if __name__ == "__main__":
