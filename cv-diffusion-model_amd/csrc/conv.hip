@@ -686,7 +686,7 @@ __global__ void __launch_bounds__(WM* WN * 64) conv3x3_kernel(const Conv3Args a)
       const int oy = oy0 + py, ox = ox0 + px;
       if (RAGGED && (oy >= Ho || ox >= Wo)) continue;
       vec_t ov = f32_to_vec<T>(v);
-      st_vec<T>(outp + ((size_t)oy * Wo + ox) * a.Cout + n0 + cv * VEC, ov);
+      st_vec_pol<T>(outp + ((size_t)oy * Wo + ox) * a.Cout + n0 + cv * VEC, ov, a.nt != 0);
 #pragma unroll
       for (int e = 0; e < VEC; ++e) {
         const float q = (float)ov[e];

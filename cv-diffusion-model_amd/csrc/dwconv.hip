@@ -221,7 +221,7 @@ __device__ __forceinline__ void dw_body_impl(const DwArgs& a, const int TYL, con
         } else {
           vec_t ov = f32_to_vec<T>(a2);
           if (!RAGGED || (col_ok && y0 + r - 2 < a.H)) {
-            st_vec<T>(out + ((size_t)(y0 + r - 2) * a.W + x0 + xl) * a.C, ov);
+            st_vec_pol<T>(out + ((size_t)(y0 + r - 2) * a.W + x0 + xl) * a.C, ov, a.nt != 0);
 #pragma unroll
             for (int e = 0; e < VEC; ++e) psum[e] += (float)ov[e];
           }

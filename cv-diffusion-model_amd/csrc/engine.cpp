@@ -546,6 +546,10 @@ int build_module(llie_ctx* c) {
 int g_use_irbx = getenv("LLIE_NO_IRBX") ? 0 : 1;
 int g_gram = 1;  // norm2 statistics of the recompute form from the Gram matrix of the block input (gram.hip); 0 = expand_stats
 int g_ztot = 1;  // SE pool as fixed-point totals + fused gate kernel (llie_tune("ztot", 0): the slab + three launches, as in training)
+// Cache policy of the big activation tensors (inference): a tensor of at least g_nt_min_mb MiB (this run's batch) is stored
+// non-temporally by its producer (common.h: st_vec_pol).  g_nt_mask picks the producers: 1 expand_dw (h2), 2 pw_expand (h1),
+// 4 dwconv3x3 (h2), 8 project / attention GEMM outputs, 16 dense 3x3 conv outputs.  Values never change, only where lines live.
+int g_nt_min_mb = 100, g_nt_mask = 1;
 int g_skip_small = 0;  // timing ablation only (results are garbage): bit 0 no gn_finalize launches, bit 1 no SE launches
 int g_irbx_mask = 0x7;  // debug: which input widths may take the recompute form (bit 0: 32, bit 1: 64, bit 2: 96 channels)
 // Backward pass: run the weight-gradient kernels on a side stream next to the activation-gradient chain
@@ -607,6 +611,9 @@ struct Run {
   template <typename T = void> T* wptr(size_t off) const { return reinterpret_cast<T*>(c->blob + off); }
   template <typename T = void> T* p(size_t off) const { return reinterpret_cast<T*>(ws + off); }
   void chk(hipError_t e) { if (e != hipSuccess && err == hipSuccess) err = e; }
+  int nt_store(int site, int64_t elems) const {  // see g_nt_min_mb
+    return !tape && (g_nt_mask & site) && g_nt_min_mb > 0 && elems * (int64_t)elem_size(dt) >= ((int64_t)g_nt_min_mb << 20) ? 1 : 0;
+  }
   size_t es() const { return elem_size(dt); }
   // launch `f` bracketed by HIP events on the launch stream when its class is being profiled
   template <typename F> void timed(int cls, int64_t bytes, F&& f, const char* nm = nullptr) {
@@ -722,7 +729,11 @@ struct Run {
         for (int i = 0; i < g.nseg; ++i) x.seg[i] = g.seg[i];
         x.nseg = g.nseg; x.wf = wptr(w.w_expand_f); x.out = g.out; x.stats = g.stats;
         x.M = M; x.N = w.hid; x.K = w.cin; x.P = P;
+        x.nt = nt_store(2, (int64_t)M * w.hid);
         timed(LLIE_K_GEMM, kbytes, [&] { return launch_pw_expand(dt, x, s); });
+      } else if (s6) {
+        g.nt = nt_store(2, (int64_t)M * w.hid);
+        timed(LLIE_K_GEMM, kbytes, [&] { return launch_pw_gemm(dt, g, s); });
       } else {
         timed(LLIE_K_GEMM, kbytes, [&] { return launch_pw_gemm(dt, g, s); });
       }
@@ -760,12 +771,14 @@ struct Run {
         xa.as2 = p<float>(as2); xa.ab2 = p<float>(ab2); xa.out = p(h2);
         xa.pool = ztot ? nullptr : p<float>(pool);
         xa.pool_tot = ztot ? p<unsigned long long>(ptot) : nullptr;
+        xa.nt = w.cin <= 64 ? nt_store(1, (int64_t)M * w.hid) : 0;  // 96 -> 384: the kernel itself loses more than its consumer gains
         timed(LLIE_K_DW, (int64_t)M * (w.cin + w.hid) * (int64_t)es(), [&] { return launch_expand_dw(dt, xa, s); });
       } else {
         DwArgs d{};
         d.in = p(h1.off); d.out = p(h2); d.as = p<float>(as2); d.ab = p<float>(ab2);
         d.w = wptr<float>(w.w_dw); d.pool = ztot ? nullptr : p<float>(pool);
         d.pool_tot = ztot ? p<unsigned long long>(ptot) : nullptr; d.B = B; d.H = H; d.W = W; d.C = w.hid; d.s6 = s6dw ? 1 : 0;
+        d.nt = nt_store(4, (int64_t)M * w.hid);
         timed(LLIE_K_DW, 2LL * M * w.hid * (int64_t)es(), [&] { return launch_dwconv3x3(dt, d, s); });
       }
     }
@@ -807,6 +820,7 @@ struct Run {
       }
       g.w = wptr(w.w_proj); g.out = p(y.off); g.stats = p<float>(y.slab);
       g.M = M; g.N = w.cout; g.P = P;
+      g.nt = nt_store(8, (int64_t)M * w.cout);
       timed(LLIE_K_GEMM, ((int64_t)M * (g.K + w.cout + (w.skip ? 0 : w.cout)) + (int64_t)w.cout * g.K) * (int64_t)es(),
             [&] { return launch_pw_gemm(dt, g, s); });
     }
@@ -898,6 +912,7 @@ struct Run {
       Conv3Args a{};
       a.in = p(x.off); a.w = wptr(w.w); a.bias = wptr<float>(w.bias); a.out = p(y.off); a.stats = p<float>(y.slab);
       a.B = B; a.Hi = x.H; a.Wi = x.W; a.Cin = w.c; a.Cout = w.c; a.mode = mode;
+      a.nt = nt_store(16, (int64_t)B * Ho * Wo * w.c);
       timed(LLIE_K_CONV3, ((int64_t)B * w.c * ((int64_t)x.H * x.W + (int64_t)Ho * Wo) + 9LL * w.c * w.c) * (int64_t)es(),
             [&] { return launch_conv3x3(dt, a, s); });
     }
@@ -2311,6 +2326,8 @@ int llie_tune(const char* knob, int value) {
   if (!strcmp(knob, "gemm_bk")) { pw_gemm_force_bk(value); return LLIE_OK; }
   if (!strcmp(knob, "gemm_bk128")) { pw_gemm_bk128(value); return LLIE_OK; }
   if (!strcmp(knob, "skip_small")) { g_skip_small = value; return LLIE_OK; }
+  if (!strcmp(knob, "nt_min_mb")) { g_nt_min_mb = value; return LLIE_OK; }
+  if (!strcmp(knob, "nt_mask")) { g_nt_mask = value; return LLIE_OK; }
   if (!strcmp(knob, "ztot")) { g_ztot = value; return LLIE_OK; }
   if (!strcmp(knob, "gram")) { g_gram = value; return LLIE_OK; }
   if (!strcmp(knob, "irbx")) { g_use_irbx = value != 0; return LLIE_OK; }
@@ -2320,7 +2337,11 @@ int llie_tune(const char* knob, int value) {
   if (!strcmp(knob, "irbx_mask")) { g_irbx_mask = value; return LLIE_OK; }
   if (!strcmp(knob, "irbx_ablate")) { irbx_ablate(value); return LLIE_OK; }
   if (!strcmp(knob, "irbx_dwv")) { irbx_dwv(value); return LLIE_OK; }
-  if (!strcmp(knob, "irbx_grid")) { irbx_grid(value); return LLIE_OK; }
+  if (!strcmp(knob, "irbx_grid")) { irbx_grid(0, value); return LLIE_OK; }
+  if (!strcmp(knob, "irbx_grid2")) { irbx_grid(2, value); return LLIE_OK; }
+  if (!strcmp(knob, "irbx_grid4")) { irbx_grid(4, value); return LLIE_OK; }
+  if (!strcmp(knob, "irbx_grid6")) { irbx_grid(6, value); return LLIE_OK; }
+  if (!strcmp(knob, "irbx_var")) { irbx_var(value); return LLIE_OK; }
   if (!strcmp(knob, "gemm_stamp")) { pw_gemm_stamp(value); return LLIE_OK; }
   if (!strcmp(knob, "pwx")) { pw_expand_enable(value); return LLIE_OK; }
   if (!strcmp(knob, "pwx_ablate")) { pw_expand_debug(value, -1); return LLIE_OK; }

@@ -86,7 +86,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[B
         for (int e = 0; e < VEC; ++e) v[e] += rr[e];
       }
       vec_t ov = f32_to_vec<T>(v);
-      if (!g.nostore) st_vec<T>(outp + o, ov);  // nostore: statistics-only pass (the consumer recomputes the tensor)
+      if (!g.nostore) st_vec_pol<T>(outp + o, ov, g.nt != 0);  // nostore: statistics-only pass (the consumer recomputes the tensor)
       if (g.stats) {
         if (dotp) {  // backward use: column sums of out * dot (e.g. d(gate) = sum_px da3 * h2) instead of sum / sum of squares
           float dd[VEC];

@@ -179,14 +179,22 @@ constexpr int kXStamps = 9;
 // DWV = form of the depthwise phase: 0 = one tap per 32x32x16 MFMA (k = 16 channels of a diagonal weight matrix),
 // 1 = two taps per 16x16x32 MFMA (k = 2 taps x 16 channels): the same ds_read_b128 data operand per MFMA, half the
 // matrix-pipe time per MFMA -> 640 instead of 1 152 pipe cycles per 64-channel chunk and wave.
-template <typename T, int KS, bool DBUF, bool STAMP = false, int ABL = 0, int DWV = 1>
+// VAR (bit mask): 1 = the 64- / 96-channel variants request the next tile's x under the last chunk's depthwise phase (sX is
+// free from that chunk's expand phase on; the registers are live for one phase only), 2 = h2 leaves with non-temporal stores.
+constexpr int kXDefaultVar = 0;
+template <typename T, int KS, bool DBUF, bool STAMP = false, int ABL = 0, int DWV = 1, int VAR = kXDefaultVar>
 __global__ void __launch_bounds__(256, (KS == 2 && !DBUF) ? 3 : 2) expand_dw_kernel(const IrbxArgs a, const int tiles_per_wg, const int chunks_per_wg) {
   constexpr int K = 16 * KS;
   constexpr int XP = (K + 8) * 2;                        // sX pixel pitch in bytes (80 / 144 / 208 / 272: conflict-free ds_read_b128)
-  constexpr int XV = kXNPX * 2 * KS;                     // 16-byte vectors of one x halo tile
-  constexpr int XPT = (XV + 255) / 256;                  // ... per thread
+  // x halo tile staging: thread -> (pixel xq0, 16-byte channel vector xkv); pass j covers pixel xq0 + j * QSTEP.  The channel
+  // vector -- hence the K segment, its base pointer and the norm1 table slice -- is the same in every pass and every tile.
+  constexpr int QSTEP = 256 / (2 * KS);                  // 64 / 32 / 21 pixels per pass
+  constexpr int XTHR = QSTEP * 2 * KS;                   // threads that take part (252 of 256 at KS = 6)
+  constexpr int XPT = (kXNPX + QSTEP - 1) / QSTEP;       // passes: 3 / 6 / 9
   constexpr int SH_BYTES = kXNPB * 32 * SHP;
-  constexpr bool PREF = KS <= 2;        // next tile's x prefetched into registers (36 VGPRs at KS = 6: not worth a spill)
+  constexpr bool PREF = KS <= 2;        // next tile's x prefetched into registers at the top of the tile
+  constexpr bool LATE = !PREF && (VAR & 1);  // ... or under the tile's last depthwise phase
+  constexpr bool NTST = (VAR & 2) != 0;
   typedef typename Elem<T>::vec_t vec_t;
   extern __shared__ __align__(16) unsigned char smem[];
   // [sH: (DBUF ? 2 : 1) x 192 x 128 B][sX: 192 x XP][wds: 9 x Chid T][aff2: 2 x Chid fp32][aff1: 2 x K fp32][red: 2 x 4 x 64 fp32]
@@ -257,28 +265,48 @@ __global__ void __launch_bounds__(256, (KS == 2 && !DBUF) ? 3 : 2) expand_dw_ker
 
   const int ntiles_img = tiles_x * (a.H / kXT_H);
   // tiles_per_wg > 0: fixed runs; <= 0: the image's tiles split evenly over the gridDim.x workgroups (knob "irbx_grid")
-  const int tile_first = tiles_per_wg > 0 ? blockIdx.x * tiles_per_wg : (int)((long)blockIdx.x * ntiles_img / gridDim.x);
-  const int tile_end = tiles_per_wg > 0 ? tile_first + tiles_per_wg : (int)((long)(blockIdx.x + 1) * ntiles_img / gridDim.x);
+  const int tile_first = tiles_per_wg > 0 ? blockIdx.x * tiles_per_wg : (int)(blockIdx.x * (unsigned)ntiles_img / gridDim.x);
+  const int tile_end = tiles_per_wg > 0 ? tile_first + tiles_per_wg : (int)((blockIdx.x + 1) * (unsigned)ntiles_img / gridDim.x);
   const int tile_last = tile_end < ntiles_img ? tile_end : ntiles_img;
 
-  // x halo tile: vector v = tid + j*256 -> pixel v / (2 KS), channel vector v % (2 KS)
-  vec_t raw[XPT];
-  auto load_tile = [&](int tile) {
-    const int ty = tile / tiles_x, tx = tile % tiles_x;
+  // x halo tile: per-thread constants of the staging -- nothing in the tile loop divides
+  const int xkv = tid % (2 * KS), xq0 = tid / (2 * KS), xk8 = xkv * 8;
+  const bool xthr = XTHR == 256 || tid < XTHR;
+  const bool xseg1 = xk8 >= a.c0;
+  const T* xb = xseg1 ? x1 + (xk8 - a.c0) : x0 + xk8;   // + pixel * xc
+  const int xc = xseg1 ? a.c1 : a.c0;
+  const bool xlast = xthr && (XPT - 1) * QSTEP + xq0 < kXNPX;   // the last pass is partial
+  int xrel[XPT];                                          // pixel offset of pass j relative to the tile's first output pixel
 #pragma unroll
-    for (int j = 0; j < XPT; ++j) {
-      const int v = tid + j * 256;
-      const int q = v / (2 * KS), k = (v % (2 * KS)) * 8;
-      const int gy = ty * kXT_H - 1 + q / kXH_W, gx = tx * kXT_W - 1 + q % kXH_W;
-      if ((XV % 256 == 0 || v < XV) && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {
-        const size_t pix = (size_t)gy * a.W + gx;
-        raw[j] = k < a.c0 ? ld_vec<T>(x0 + pix * a.c0 + k) : ld_vec<T>(x1 + pix * a.c1 + (k - a.c0));
-      } else {
-        raw[j] = vec_t{};  // outside the image: h1 is forced to zero there (ok[] below), the value is irrelevant
+  for (int j = 0; j < XPT; ++j) {
+    const int q = xq0 + j * QSTEP;
+    xrel[j] = (q / kXH_W - 1) * a.W + (q % kXH_W - 1);
+  }
+  unsigned char* sxw = sX + xq0 * XP + xk8 * 2;
+  vec_t raw[XPT];
+  // (ty, tx) = tile coordinates; interior tiles need no bounds checks
+  auto load_tile = [&](int ty, int tx) {
+    const int pix0 = ty * kXT_H * a.W + tx * kXT_W;
+    const bool border = ty == 0 || tx == 0 || ty == a.H / kXT_H - 1 || tx == tiles_x - 1;
+    if (!border) {
+#pragma unroll
+      for (int j = 0; j < XPT; ++j) {
+        if (j < XPT - 1 ? xthr : xlast) raw[j] = ld_vec<T>(xb + (size_t)(pix0 + xrel[j]) * xc);
+        else raw[j] = vec_t{};
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < XPT; ++j) {
+        const int q = xq0 + j * QSTEP;
+        const int gy = ty * kXT_H - 1 + q / kXH_W, gx = tx * kXT_W - 1 + q % kXH_W;
+        // outside the image: h1 is forced to zero there (ok[] below), the value is irrelevant
+        if ((j < XPT - 1 ? xthr : xlast) && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) raw[j] = ld_vec<T>(xb + (size_t)(pix0 + xrel[j]) * xc);
+        else raw[j] = vec_t{};
       }
     }
   };
-  if (PREF && tile_first < tile_last) load_tile(tile_first);
+  int ty = tile_first / tiles_x, tx = tile_first % tiles_x;   // the only division: once per workgroup
+  if ((PREF || LATE) && tile_first < tile_last) load_tile(ty, tx);
   // weight slices (A operand) of the chunk about to run.  They are always fetched one depthwise phase ahead and BEFORE
   // that phase's stores: the wait in front of the MFMAs then leaves the (younger) stores in flight instead of draining them.
   vec_t wf[KS];
@@ -336,11 +364,12 @@ __global__ void __launch_bounds__(256, (KS == 2 && !DBUF) ? 3 : 2) expand_dw_ker
   };
 
   for (int tile = tile_first; tile < tile_last; ++tile) {
-    const int ty = tile / tiles_x, tx = tile % tiles_x;
     const int y0 = ty * kXT_H, x0p = tx * kXT_W;
+    int tyn = ty, txn = tx + 1;  // the next tile of the run
+    if (txn == tiles_x) { txn = 0; ++tyn; }
     // ---- activate this tile's x (norm1 + ReLU6) into sX, prefetch the next tile.  Every wave is past the last
     // MFMA phase of the previous tile here (the barrier that follows it), so sX is free.
-    if (!PREF) load_tile(tile);
+    if (!PREF && !LATE) load_tile(ty, tx);
     // Every vector-memory operation so far has to be complete here anyway (raw[] below is older than all of them), but the
     // compiler's wait sits inside the predicated block below; said unconditionally, the chunk loop is entered with nothing
     // pending, and the wait for the prefetched weight slices at its head becomes vmcnt(4 + ...) -- the depthwise phase's four
@@ -349,22 +378,21 @@ __global__ void __launch_bounds__(256, (KS == 2 && !DBUF) ? 3 : 2) expand_dw_ker
     stamp(0);
 #pragma unroll
     for (int j = 0; j < XPT; ++j) {
-      const int v = tid + j * 256;
-      if (XV % 256 == 0 || v < XV) {
-        const int q = v / (2 * KS), k = (v % (2 * KS)) * 8;
-        *reinterpret_cast<vec_t*>(sX + q * XP + k * 2) = activate8<T>(raw[j], aff1 + k, aff1 + K + k);
-      }
+      if (j < XPT - 1 ? xthr : xlast)
+        *reinterpret_cast<vec_t*>(sxw + j * QSTEP * XP) = activate8<T>(raw[j], aff1 + xk8, aff1 + K + xk8);
     }
     stamp(1);
-    if (PREF && tile + 1 < tile_last) load_tile(tile + 1);
-    // validity of this lane's three halo pixels (zero padding of the depthwise input)
+    if (PREF && tile + 1 < tile_last) load_tile(tyn, txn);
+    // validity of this lane's three halo pixels (zero padding of the depthwise input): border tiles only
     const bool border = ty == 0 || tx == 0 || ty == a.H / kXT_H - 1 || tx == tiles_x - 1;
-    bool ok[3];
+    bool ok[3] = {true, true, true};
+    if (border) {
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      const int q = (pxg * 3 + i) * 32 + n;
-      const int gy = y0 - 1 + q / kXH_W, gx = x0p - 1 + q % kXH_W;
-      ok[i] = q < kXNPX && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+      for (int i = 0; i < 3; ++i) {
+        const int q = (pxg * 3 + i) * 32 + n;
+        const int gy = y0 - 1 + q / kXH_W, gx = x0p - 1 + q % kXH_W;
+        ok[i] = q < kXNPX && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+      }
     }
     stamp(2);
     tile_barrier();
@@ -446,6 +474,9 @@ __global__ void __launch_bounds__(256, (KS == 2 && !DBUF) ? 3 : 2) expand_dw_ker
       stamp(6);
       tile_barrier();
       if (DBUF) flush_pool();
+      if constexpr (LATE) {  // sX has been read for the last time in this tile: its next contents are requested under the depthwise phase
+        if (chunk + 1 == chunk1 && tile + 1 < tile_last) load_tile(tyn, txn);
+      }
       stamp(7);
       // ---- depthwise 3x3 on the MFMA pipe.  The VALU is what this kernel runs out of (a wave64 instruction costs a SIMD
       // 4 cycles; 72 FMAs per 16 output bytes), the matrix pipe idles.  A depthwise tap is a diagonal matrix:
@@ -530,8 +561,9 @@ __global__ void __launch_bounds__(256, (KS == 2 && !DBUF) ? 3 : 2) expand_dw_ker
           const int orow = 4 * pxg + r;
           T* op = out + ((size_t)(y0 + orow) * a.W + x0p + li) * a.Chid + chunk * 64 + chb * 32 + choff;
           if constexpr ((ABL & 4) != 0) op = out + ((size_t)orow * a.W + x0p + li) * a.Chid + chunk * 64 + chb * 32 + choff;
-          if constexpr (!(ABL & 1)) *reinterpret_cast<u32x4*>(op) = v;
-          else asm volatile("" :: "v"(v));
+          if constexpr (ABL & 1) asm volatile("" :: "v"(v));
+          else if constexpr (NTST) __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(op));
+          else *reinterpret_cast<u32x4*>(op) = v;
         }
         // SE pool partial: channel sums over the wave's 64 pixels -- the 4 rows in registers, then the 16 pixel lanes of a row by DPP
         if (has_pool && !(ABL & 2)) {
@@ -688,6 +720,7 @@ __global__ void __launch_bounds__(256, (KS == 2 && !DBUF) ? 3 : 2) expand_dw_ker
       if (DBUF) par ^= 1;
       stamp(8);
     }
+    ty = tyn; tx = txn;
   }
   if constexpr (STAMP) {
     if (a.dbg && lane == 0) {
@@ -723,8 +756,14 @@ int irbx_stats_rows(int P) {
   return rp;
 }
 
-static int g_irbx_dbuf = 0, g_irbx_tiles = 4, g_irbx_stamp = 0, g_irbx_ablate = 0, g_irbx_dwv = 1, g_irbx_grid = 0;
-void irbx_grid(int v) { g_irbx_grid = v; }
+static int g_irbx_dbuf = 0, g_irbx_tiles = 4, g_irbx_stamp = 0, g_irbx_ablate = 0, g_irbx_dwv = 1;
+static int g_irbx_grid[3] = {0, 0, 0};  // per input width (32, 64, 96 channels)
+void irbx_grid(int ks, int v) {
+  for (int i = 0; i < 3; ++i)
+    if (ks == 0 || ks == 2 * (i + 1)) g_irbx_grid[i] = v;
+}
+static int g_irbx_var = kXDefaultVar;
+void irbx_var(int v) { g_irbx_var = v; }
 void irbx_dwv(int v) { g_irbx_dwv = v; }
 void irbx_ablate(int v) { g_irbx_ablate = v; }
 static unsigned long long* g_irbx_dbg = nullptr;
@@ -788,8 +827,8 @@ static hipError_t launch_dw_cfg(const IrbxArgs& a, hipStream_t s) {
                                   (DBUF ? "1" : "0") + ">";
   note_kernel(name.c_str());
   dim3 grid(ntiles / tpw, nchunks / cpw, a.B);
-  if (g_irbx_grid > 0) {  // knob "irbx_grid": about this many workgroups per launch, each image's tiles split evenly over its share
-    int gx = g_irbx_grid / (a.B * (nchunks / cpw));
+  if (g_irbx_grid[KS / 2 - 1] > 0) {  // knobs "irbx_grid", "irbx_grid2/4/6": about this many workgroups per launch, each image's tiles split evenly over its share
+    int gx = g_irbx_grid[KS / 2 - 1] / (a.B * (nchunks / cpw));
     gx = gx < 1 ? 1 : (gx > ntiles ? ntiles : gx);
     grid.x = gx;
     tpw = 0;
@@ -837,6 +876,23 @@ static hipError_t launch_dw_cfg(const IrbxArgs& a, hipStream_t s) {
       return e;
     hipLaunchKernelGGL((expand_dw_kernel<T, KS, DBUF, false, 0, 0>), grid, dim3(256), lds, s, a, tpw, cpw);
     return hipGetLastError();
+  }
+  if constexpr (!DBUF) {
+    if (g_irbx_var != kXDefaultVar || a.nt) {  // knob "irbx_var": A/B of the variants (see VAR); IrbxArgs::nt = bit 2
+      auto go = [&](auto kern) -> hipError_t {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a, tpw, cpw);
+        return hipGetLastError();
+      };
+      switch (g_irbx_var | (a.nt ? 2 : 0)) {
+        case 0: return go(&expand_dw_kernel<T, KS, DBUF, false, 0, 1, 0>);
+        case 1: return go(&expand_dw_kernel<T, KS, DBUF, false, 0, 1, 1>);
+        case 2: return go(&expand_dw_kernel<T, KS, DBUF, false, 0, 1, 2>);
+        case 3: return go(&expand_dw_kernel<T, KS, DBUF, false, 0, 1, 3>);
+      }
+      return hipErrorInvalidValue;
+    }
   }
   hipLaunchKernelGGL((expand_dw_kernel<T, KS, DBUF>), grid, dim3(256), lds, s, a, tpw, cpw);
   return hipGetLastError();

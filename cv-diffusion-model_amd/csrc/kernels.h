@@ -51,6 +51,7 @@ struct GemmArgs {
   int nostore;        // 1: compute and write only the statistics slab (out may be null)
   int dbg;            // timing ablations (set by the launcher from pw_gemm_debug; 0 in production)
   const void* dot;    // optional [M][N] T: the slab then holds (sum out*dot, sum out) instead of (sum, sum of squares)
+  int nt;             // 1: `out` is stored non-temporally (set by the engine for tensors beyond the Infinity Cache, common.h: st_vec_pol)
   unsigned long long* stamps;  // diagnostic builds only (pw_gemm_stamp)
 };
 void pw_gemm_stamp(int v);
@@ -73,6 +74,7 @@ struct ExpandArgs {
   float* stats;
   int M, N, K, P;
   int nsplit;  // set by the launcher
+  int nt;      // 1: non-temporal output stores (see GemmArgs::nt)
   unsigned long long* stamps;  // diagnostic builds only (pw_expand_debug)
 };
 __host__ __device__ inline long long pw_expand_pack_index(int n, int k, int K) {
@@ -125,6 +127,7 @@ struct DwArgs {
   // backward epilogue (all four set, pool null): out = conv * [0 < bx*bas + bab < 6], and
   // bslab[b][tile][0][c] = sum out, [1][c] = sum out*bx over 8-row segments (tile = dwconv_ntiles numbering)
   const void* bx; const float* bas; const float* bab; float* bslab;
+  int nt;            // 1: non-temporal output stores (see GemmArgs::nt)
 };
 hipError_t launch_dwconv3x3(int dtype, const DwArgs& a, hipStream_t s);
 
@@ -167,9 +170,11 @@ struct IrbxArgs {
   int B, H, W, Chid;
   unsigned long long* dbg;                       // diagnostic builds only (irbx_stamp)
   int ablate;                                    // timing ablations (results wrong when non-zero; 0 in production)
+  int nt;                                        // 1: h2 is stored non-temporally (see GemmArgs::nt)
 };
 void irbx_ablate(int v);
-void irbx_grid(int v);   // knob "irbx_grid": workgroups per expand_dw launch (0 = heuristics); each image's tiles are split evenly
+void irbx_grid(int ks, int v);   // knobs "irbx_grid" (ks = 0: all), "irbx_grid2/4/6": workgroups per expand_dw launch (0 = heuristics)
+void irbx_var(int v);    // knob "irbx_var": expand_dw variant bits (irbx.hip: VAR)
 void irbx_dwv(int v);  // depthwise phase of expand_dw: 1 = two taps per 16x16x32 MFMA (default), 0 = one tap per 32x32x16 MFMA
 void irbx_stamp(int v);
 hipError_t irbx_stamp_fetch(double* out10);  // 9 slots (irbx.hip: STAMP) + the number of waves averaged
@@ -261,6 +266,7 @@ struct Conv3Args {
   float* stats;        // slab of out or null
   int B, Hi, Wi, Cin, Cout;
   int mode;
+  int nt;              // 1: non-temporal output stores (see GemmArgs::nt)
 };
 hipError_t launch_conv3x3(int dtype, const Conv3Args& a, hipStream_t s);
 int conv3x3_ntiles(int Ho, int Wo);

@@ -281,8 +281,13 @@ __global__ void __launch_bounds__(256, 2) pw_expand_kernel(const ExpandArgs g) {
           // memory operations per thread only, so pin the order here
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
           T* orow = reinterpret_cast<T*>(g.out) + (m0 + wave * 32 + (lane >> 3)) * g.N + nbase + ((it * NBW + j) >> 1) * 64 + (lane & 7) * 8;
+          if (g.nt) {  // uniform
 #pragma unroll
-          for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(orow + (size_t)(8 * i) * g.N) = rowv[i];
+            for (int i = 0; i < 4; ++i) __builtin_nontemporal_store(rowv[i], reinterpret_cast<u32x4*>(orow + (size_t)(8 * i) * g.N));
+          } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(orow + (size_t)(8 * i) * g.N) = rowv[i];
+          }
         }
       }
     }
