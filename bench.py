@@ -432,6 +432,27 @@ def kernel_class_of(name: str, native) -> int:
     return native.K_OTHER
 
 
+def kernel_family_of(name: str) -> str:
+    """Kernel family of a launcher-recorded kernel name (roofline.families)."""
+    if name.startswith(("pw_gemm", "pw_expand")):
+        return "pointwise GEMM (pw_gemm + pw_expand)"
+    if name.startswith("expand_dw"):
+        return "expand_dw (recompute expand + depthwise)"
+    if name.startswith(("expand_stats", "gram_stats")):
+        return "norm2 statistics passes (gram_stats, expand_stats)"
+    if name.startswith("dwconv3x3"):
+        return "dwconv3x3"
+    if name.startswith("conv3x3"):
+        return "dense 3x3 convs (down / up-sampling)"
+    if name.startswith(("init_conv", "final_conv")):
+        return "input / output heads"
+    if name.startswith(("gn_finalize", "gram_finalize", "se_", "time_embed", "film", "zero_fill")):
+        return "small launches (finalize, SE, time / FiLM)"
+    if name.startswith(("linattn", "affine_add")):
+        return "linear attention"
+    return "other"
+
+
 def pmc_lookup(kernels: dict, name: str):
     """HBM bytes per launch of kernel `name` in a tools/pmc_summary.py table.  Its demangler prints template arguments it
     cannot resolve (bool / defaulted ones) as `?`: `pw_gemm_kernel<_Float16, 128, 128, 2, 2, 64, ?, ?, ?>` is the launcher's
@@ -450,16 +471,21 @@ def roofline(handle, native, args, breakdown, dom_prof, step_seconds: float, pea
     in a pass of `--steps` steps right AFTER the timed region, because the timed region itself replays a hipGraph whose
     kernels cannot be bracketed individually.  `achieved` = algorithmic bytes of that kernel's recorded launches / their
     summed device time (byte model per kernel: DESIGN.md section 3).  `traffic` = measured HBM bytes per launch from the
-    committed PMC passes of this same command (profiles/r03/pmc_traffic.json, else round 2's; FETCH_SIZE x2 + WRITE_SIZE, see
+    committed PMC passes of this same command (profiles/r04/pmc_traffic.json, else an earlier round's; FETCH_SIZE x2 + WRITE_SIZE, see
     tools/pmc_summary.py), else null.  `whole_path` is the same quotient for everything `enhance` does, measured over the
-    timed region itself: lcm_steps x llie_algorithmic_bytes (SURVEY.md 8d's byte model) / the step time."""
+    timed region itself: `whole_path.frac` = lcm_steps x llie_path_bytes (the bytes the engine's own launch sequence has to
+    move: recompute blocks charged 3Cin + 2Chid + Cout, since round 3) / the step time; the reference-shaped model of SURVEY.md
+    8d (llie_algorithmic_bytes: h1 written and read, what round 2's `whole_path.frac` used) is `whole_path.materialised_model`.
+    `families` = share of the step and achieved GB/s per kernel family (the per-instantiation split of `kernel` hides that the
+    pointwise-GEMM family and expand_dw are larger than the dominant instantiation); `worst` = the kernel with at least
+    5 % of the step that is furthest below the HBM roof."""
     if not dom_prof:
         return None
     dom = max(dom_prof, key=lambda k: dom_prof[k][0])
     ms, n, nbytes = dom_prof[dom]
     achieved = nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
     traffic = None
-    pmc = next((q for q in (os.path.join(ROOT, "profiles", r, "pmc_traffic.json") for r in ("r03", "r02")) if os.path.exists(q)), "")
+    pmc = next((q for q in (os.path.join(ROOT, "profiles", r, "pmc_traffic.json") for r in ("r04", "r03", "r02")) if os.path.exists(q)), "")
     default_cfg = (args.variant, args.image_size, args.batch, args.lcm_steps, args.dtype) == ("small", 256, 32, 4, "fp16")
     if default_cfg and os.path.exists(pmc):
         traffic = pmc_lookup(json.load(open(pmc)).get("kernels", {}), dom)
@@ -485,6 +511,22 @@ def roofline(handle, native, args, breakdown, dom_prof, step_seconds: float, pea
                                                  "frac_of_measured": round(whole / peak_measured, 4)}}}
     if breakdown:  # one post-timing step with every class armed
         tot = sum(v[0] for v in breakdown.values())
+        fams = {}
+        for k, v in breakdown.items():
+            f = fams.setdefault(kernel_family_of(k), [0.0, 0, 0])
+            f[0] += v[0]; f[1] += v[1]; f[2] += v[2]
+        out["families"] = {k: {"ms": round(v[0], 3), "launches": v[1], "share": round(v[0] / tot, 3),
+                               "GBps": round(v[2] / (v[0] * 1e-3) / 1e9, 1) if v[0] > 0 and v[2] > 0 else None,
+                               "frac": round(v[2] / (v[0] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if v[0] > 0 and v[2] > 0 else None}
+                           for k, v in sorted(fams.items(), key=lambda kv: -kv[1][0])}
+        big = {k: v for k, v in breakdown.items() if v[0] / tot >= 0.05 and v[2] > 0}
+        if big:
+            wk = min(big, key=lambda k: big[k][2] / big[k][0])
+            wv = big[wk]
+            out["worst"] = {"kernel": wk, "share": round(wv[0] / tot, 3), "avg_launch_us": round(1e3 * wv[0] / wv[1], 2),
+                            "achieved": round(wv[2] / (wv[0] * 1e-3) / 1e9, 1),
+                            "frac": round(wv[2] / (wv[0] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                            "note": "kernel with >= 5 % of the step furthest below the 8 TB/s roof (algorithmic bytes / event time)"}
         out["step_breakdown"] = {k: {"ms": round(v[0], 3), "launches": v[1], "avg_us": round(1e3 * v[0] / v[1], 2),
                                      "GBps": round(v[2] / (v[0] * 1e-3) / 1e9, 1) if v[0] > 0 else None,
                                      "share": round(v[0] / tot, 3)}

@@ -25,7 +25,7 @@ EXPORTS = [
     "llie_profile_begin", "llie_profile_end", "llie_enhance_workspace_bytes",
     "llie_preprocess_u8", "llie_postprocess_u8", "llie_profile_report", "llie_pw_gemm", "llie_pw_gemm_tile_rows", "llie_dwconv3x3", "llie_dwconv3x3_tiles", "llie_tune",
     "llie_grad_numel", "llie_param_grad_offset", "llie_train_workspace_bytes", "llie_unet_train_forward",
-    "llie_unet_backward", "llie_module_backward", "llie_load_all", "llie_profile_dump", "llie_copy_probe", "llie_rw_probe", "llie_pw_expand", "llie_gram_stats", "llie_gram_part_floats", "llie_groupnorm_finalize", "llie_conv3x3", "llie_conv3x3_tiles", "llie_linattn", "llie_linattn_splits", "llie_se_mlp", "llie_film", "llie_refresh_params", "llie_path_bytes", "llie_time_embed", "llie_debug_irbx_stamps", "llie_debug_gemm_stamps", "llie_debug_pwx_stamps",
+    "llie_unet_backward", "llie_module_backward", "llie_load_all", "llie_profile_dump", "llie_copy_probe", "llie_rw_probe", "llie_pw_expand", "llie_gram_stats", "llie_gram_part_floats", "llie_groupnorm_finalize", "llie_conv3x3", "llie_conv3x3_tiles", "llie_linattn", "llie_linattn_splits", "llie_se_mlp", "llie_film", "llie_refresh_params", "llie_path_bytes", "llie_time_embed", "llie_debug_irbx_stamps", "llie_debug_gemm_stamps", "llie_debug_pwx_stamps", "llie_graph_cache_entries", "llie_gram_finalize",
 ]
 K_GEMM, K_DW, K_CONV3, K_SE, K_OTHER = 1, 2, 4, 8, 16
 
@@ -107,6 +107,7 @@ def lib() -> C.CDLL:
     L.llie_pw_expand.argtypes = [ci, C.POINTER(GemmSeg), ci, vp, vp, vp, vp, ci, ci, ci, vp]
     L.llie_gram_stats.argtypes = [ci, vp, ci, vp, ci, vp, vp, ci, ci, vp, vp, vp, vp]
     L.llie_gram_part_floats.argtypes = [ci, ci]
+    L.llie_gram_finalize.argtypes = [ci, vp, vp, ci, ci, vp, vp, vp, i64, C.c_float, C.c_float, ci, vp, vp, vp]
     L.llie_groupnorm_finalize.argtypes = [vp, ci, ci, vp, ci, ci, ci, ci, vp, vp, vp, i64, C.c_float, C.c_float, ci, vp, vp, vp]
     L.llie_conv3x3.argtypes = [ci, ci, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp]
     L.llie_conv3x3_tiles.argtypes = [ci, ci]
@@ -119,6 +120,8 @@ def lib() -> C.CDLL:
     L.llie_dwconv3x3_tiles.argtypes = [ci, ci]
     L.llie_tune.argtypes = [C.c_char_p, ci]
     L.llie_debug_irbx_stamps.argtypes = [C.POINTER(C.c_double)]
+    L.llie_graph_cache_entries.argtypes = [C.c_void_p]
+    L.llie_graph_cache_entries.restype = C.c_int
     L.llie_debug_gemm_stamps.argtypes = [C.POINTER(C.c_double)]
     L.llie_grad_numel.argtypes = [vp]
     L.llie_grad_numel.restype = i64

@@ -210,7 +210,11 @@ struct llie_ctx {
   size_t init_wp = 0, fin_wp = 0;  // MFMA-packed init / final conv weights (2-byte compute dtypes)
   size_t init_w = 0, init_b = 0, fin_g = 0, fin_b = 0, fin_w = 0, fin_bias = 0;
   // hipGraph cache of llie_enhance launch sequences (key -> executable graph)
-  struct GraphEntry { bool seen = false; hipGraphExec_t exec = nullptr; hipGraph_t graph = nullptr; };
+  // bounded: least-recently-used entries beyond kMaxGraphs are destroyed (a server sweeping batch sizes or schedules would
+  // otherwise grow it without limit; an evicted key is simply captured again on its second next use)
+  struct GraphEntry { bool seen = false; hipGraphExec_t exec = nullptr; hipGraph_t graph = nullptr; uint64_t used = 0; };
+  static constexpr size_t kMaxGraphs = 16;
+  uint64_t graph_clock = 0;
   std::map<std::string, GraphEntry> graphs;
   std::map<std::tuple<int, int64_t, int>, size_t> zneed;  // (batch, pixels, knob epoch) -> bytes of zero-initialised totals one forward takes (Run::zbegin)
   hipStream_t cap_stream = nullptr;  // side stream used only to record captures (the legacy null stream cannot capture)
@@ -302,7 +306,7 @@ struct Builder {
     w.n1g = f32(p + ".norm1.weight", cin_r, w.cin); w.n1b = f32(p + ".norm1.bias", cin_r, w.cin);
     w.n2g = f32(p + ".norm2.weight", w.hid_r, w.hid); w.n2b = f32(p + ".norm2.bias", w.hid_r, w.hid);
     w.w_expand = mat(p + ".expand.weight", w.hid_r, cin_r, &w.w_expand_t, w.hid, w.cin);
-    if (c->dt != LLIE_F32 && w.hid == w.hid_r && w.cin == cin_r && w.cin >= 128 && w.cin % 64 == 0 && w.hid % 32 == 0) {
+    if (c->dt != LLIE_F32 && w.hid == w.hid_r && w.cin == cin_r && pw_expand_serves_k(w.cin) && w.hid % 64 == 0) {
       // wide blocks of the 2-byte engines: the expand GEMM runs activation-stationary (pwx.hip) from this packed copy
       w.has_wf = true;
       w.w_expand_f = reserve((size_t)w.hid * w.cin * es());
@@ -2071,7 +2075,17 @@ int llie_enhance(llie_ctx* c, const float* low, const float* noise, const int64_
   snprintf(tail, sizeof tail, "|%d|%d|%d|%d|%p|%lld|%d|%d", batch, steps, inter ? 1 : 0, preds ? 1 : 0, ws, (long long)ws_bytes,
            g_enhance_split, tune_epoch());
   key += tail;
+  if (c->graphs.find(key) == c->graphs.end() && c->graphs.size() >= llie_ctx::kMaxGraphs) {  // evict the least recently used entry
+    auto lru = c->graphs.begin();
+    for (auto it = c->graphs.begin(); it != c->graphs.end(); ++it)
+      if (it->second.used < lru->second.used) lru = it;
+    if (lru->second.exec || lru->second.graph) (void)hipDeviceSynchronize();  // a replay of it may still be in flight (on any stream); evictions are rare
+    if (lru->second.exec) (void)hipGraphExecDestroy(lru->second.exec);
+    if (lru->second.graph) (void)hipGraphDestroy(lru->second.graph);
+    c->graphs.erase(lru);
+  }
   llie_ctx::GraphEntry& ge = c->graphs[key];
+  ge.used = ++c->graph_clock;
   if (!ge.seen) {
     ge.seen = true;
     return enhance_sequence(c, low, noise, t_dev, coefs, steps, enhanced, inter, preds, batch, base, ws_bytes, stream);
@@ -2228,13 +2242,27 @@ static int kerr(const char* what, hipError_t e) {
 int llie_groupnorm_finalize(const float* slab0, int ntiles0, int ch0, const float* slab1, int ntiles1, int ch1, int groups, int pixels,
                             const float* gamma, const float* beta, const float* film, int64_t film_stride, float eps, float post_scale,
                             int batch, float* scale_out, float* shift_out, llie_stream stream) {
-  if (!slab0 || !gamma || !beta || !scale_out || !shift_out || batch <= 0 || ch0 <= 0 || (slab1 && ch1 <= 0)) return LLIE_ERR_ARG;
+  if (!slab0 || !gamma || !beta || !scale_out || !shift_out || batch <= 0 || ch0 <= 0 || (slab1 && ch1 <= 0) || groups <= 0 || pixels <= 0 ||
+      ntiles0 <= 0 || (slab1 && ntiles1 <= 0) || (ch0 + (slab1 ? ch1 : 0)) % groups)
+    return LLIE_ERR_ARG;
   GnFinalizeArgs a{};
   a.src[0] = StatSrc{slab0, ntiles0, ch0};
   if (slab1) a.src[1] = StatSrc{slab1, ntiles1, ch1};
   a.C = ch0 + (slab1 ? ch1 : 0); a.groups = groups; a.P = pixels; a.gamma = gamma; a.beta = beta; a.film = film; a.film_stride = film_stride;
   a.eps = eps; a.as = scale_out; a.ab = shift_out; a.B = batch; a.post_scale = post_scale;
   return kerr("groupnorm_finalize", launch_gn_finalize(a, reinterpret_cast<hipStream_t>(stream)));
+}
+// GroupNorm-2 + FiLM affine of the recompute form from the Gram totals llie_gram_stats leaves (gram.hip: gram_finalize_kernel)
+int llie_gram_finalize(int dtype, const float* gram_totals, const void* w_expand, int K, int pixels, const float* gamma, const float* beta,
+                       const float* film, int64_t film_stride, float eps, float post_scale, int batch, float* scale_out, float* shift_out,
+                       llie_stream stream) {
+  if (!gram_totals || !w_expand || !gamma || !beta || !scale_out || !shift_out || batch <= 0 || pixels <= 0 || (K != 32 && K != 64 && K != 96) ||
+      (dtype != 1 && dtype != 2))
+    return LLIE_ERR_ARG;
+  GramFinalizeArgs a{};
+  a.gtot = gram_totals; a.w1 = w_expand; a.K = K; a.Chid = 4 * K; a.groups = 32; a.P = pixels; a.B = batch; a.gamma = gamma; a.beta = beta;
+  a.film = film; a.film_stride = film_stride; a.eps = eps; a.as = scale_out; a.ab = shift_out; a.post_scale = post_scale;
+  return kerr("gram_finalize", launch_gram_finalize(dtype, a, reinterpret_cast<hipStream_t>(stream)));
 }
 int llie_conv3x3(int dtype, int mode, const void* in, const void* w, const float* bias, void* out, float* stats, int batch, int Hi, int Wi,
                  int Cin, int Cout, llie_stream stream) {
@@ -2368,6 +2396,9 @@ int llie_debug_pwx_stamps(double* out4) {
   if (e == hipSuccess) e = pw_expand_stamp_fetch(out4);
   return e == hipSuccess ? LLIE_OK : LLIE_ERR_ARG;
 }
+
+// number of entries in the context's hipGraph cache (bounded by kMaxGraphs, least recently used evicted)
+int llie_graph_cache_entries(const llie_ctx* c) { return c ? (int)c->graphs.size() : LLIE_ERR_ARG; }
 
 // diagnostic: mean per-wave cycles of the last stamped expand_dw launch (llie_tune("irbx_stamp", 1)); synchronises
 int llie_debug_irbx_stamps(double* out10) {

@@ -286,9 +286,11 @@ __global__ void __launch_bounds__(256) gram_finalize_kernel(const GramFinalizeAr
   for (int c = 0; c < CPW; ++c) s1[c] = s2[c] = 0.0;
   for (int i = lane; i < K; i += 64) {
     const float* gr = sG + i * KP;
-    float t[CPW];
+    // in fp64: G's entries are all positive (up to P) while w has mixed signs, so the cancellation of the quadratic form
+    // starts in this row product; at K <= 96 the kernel is latency-bound and the wider arithmetic costs nothing measurable
+    double t[CPW];
 #pragma unroll
-    for (int c = 0; c < CPW; ++c) t[c] = 0.f;
+    for (int c = 0; c < CPW; ++c) t[c] = 0.0;
 #pragma unroll 4
     for (int j = 0; j < K; j += 4) {
       const f32x4 g4 = *reinterpret_cast<const f32x4*>(gr + j);
@@ -296,13 +298,13 @@ __global__ void __launch_bounds__(256) gram_finalize_kernel(const GramFinalizeAr
       for (int c = 0; c < CPW; ++c) {
         const f32x4 w4 = *reinterpret_cast<const f32x4*>(sw + (wave * CPW + c) * K + j);  // same address in every lane
 #pragma unroll
-        for (int e = 0; e < 4; ++e) t[c] = __builtin_fmaf(g4[e], w4[e], t[c]);
+        for (int e = 0; e < 4; ++e) t[c] = __builtin_fma((double)g4[e], (double)w4[e], t[c]);
       }
     }
 #pragma unroll
     for (int c = 0; c < CPW; ++c) {
       const double wi = (double)sw[(wave * CPW + c) * K + i];
-      s2[c] += wi * (double)t[c];
+      s2[c] += wi * t[c];
       s1[c] += wi * (double)sm[i];
     }
   }

@@ -579,7 +579,10 @@ __global__ void __launch_bounds__(256, (KS == 2 && !DBUF) ? 3 : 2) expand_dw_ker
 #define LLIE_DPP_STEP(ROR)                                                                                               \
   _Pragma("unroll") for (int i = 0; i < 8; ++i)                                                                          \
       asm volatile("v_add_f32_dpp %0, %0, %0 row_ror:" #ROR " row_mask:0xf bank_mask:0xf" : "+v"(v[i]));
-          asm volatile("s_nop 1");  // the sums just written by ordinary VALU adds: 2 wait states before the first DPP read
+          // the sums just written by ordinary VALU adds: 2 wait states before the first DPP read.  The eight values are operands of
+          // the statement, so every add that produces them is scheduled ABOVE the nop (a bare volatile asm orders only against
+          // other side effects, and hipcc's hazard recognizer does not look inside inline asm for the DPP read).
+          asm volatile("s_nop 1" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]));
           LLIE_DPP_STEP(8)
           LLIE_DPP_STEP(4)
           LLIE_DPP_STEP(2)

@@ -82,6 +82,7 @@ __host__ __device__ inline long long pw_expand_pack_index(int n, int k, int K) {
   return ((((long long)(n >> 5) * (K >> 4) + (k >> 4)) * 64 + lane) << 3) + (k & 7);
 }
 bool pw_expand_supported(int dtype, const GemmSeg* seg, int nseg, int M, int N, int K, int P);
+bool pw_expand_serves_k(int K);  // the kernel exists for this input width (the builder packs the fragment-ordered weight copy only then)
 hipError_t launch_pw_expand(int dtype, const ExpandArgs& a, hipStream_t s);
 hipError_t launch_pack_expand(int dtype, const float* src, void* dst, int N, int K, float scale, hipStream_t s);
 void pw_expand_enable(int v);  // knob "pwx" (1 = use where supported)

@@ -364,6 +364,7 @@ static int nsplit_for(int M, int N, int nbw) {
   while ((long)(M / 128) * ns < 512 && (N / (32 * nbw)) % (2 * ns) == 0 && N / (32 * nbw * 2 * ns) >= 2 && (N / (2 * ns)) % 64 == 0) ns *= 2;
   return ns;
 }
+bool pw_expand_serves_k(int K) { return K == 128 || K == 192 || K == 256 || K == 384 || K == 512; }
 bool pw_expand_supported(int dtype, const GemmSeg* seg, int nseg, int M, int N, int K, int P) {
   if (!g_use_pwx || (dtype != 1 && dtype != 2) || nseg < 1 || nseg > 3 || P % 128 || M % P) return false;
   const int nbw = nbw_for(K);

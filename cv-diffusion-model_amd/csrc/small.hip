@@ -135,7 +135,9 @@ __global__ void __launch_bounds__(256) gn_finalize_kernel(const GnFinalizeArgs a
 }
 
 hipError_t launch_gn_finalize(const GnFinalizeArgs& a, hipStream_t s) {
-  if ((a.Creal > 0 ? a.Creal : a.C) % a.groups || a.groups <= 0 || a.Creal > a.C) return hipErrorInvalidValue;
+  if (a.groups <= 0 || a.P <= 0 || a.B <= 0 || a.Creal > a.C || (a.Creal > 0 ? a.Creal : a.C) % a.groups) return hipErrorInvalidValue;
+  for (int i = 0; i < 2; ++i)
+    if (a.src[i].slab && (a.src[i].ntiles <= 0 || a.src[i].ch <= 0)) return hipErrorInvalidValue;
   int c = 0;
   for (int i = 0; i < 2; ++i)
     if (a.src[i].slab) c += a.src[i].ch;

@@ -184,10 +184,13 @@ int llie_add_noise(const float* x0, const float* noise, const int64_t* timesteps
  * When the workspace has llie_enhance_workspace_bytes() the launch sequence is captured into a hipGraph
  * on its second use for a given (batch, schedule, workspace, stream) and replayed afterwards; user
  * tensors are staged through the workspace so the graph's pointers never change
- * (LLIE_NO_GRAPH=1 in the environment disables this). */
+ * (LLIE_NO_GRAPH=1 in the environment disables this).  The cache of captured graphs holds at most 16 entries per
+ * context; the least recently used one is destroyed when a 17th key appears (llie_graph_cache_entries reads the count). */
 int llie_enhance(llie_ctx* ctx, const float* low_light, const float* noise, const int64_t* timesteps_dev,
                  const llie_step_coef* coefs, int steps, float* enhanced, float* intermediates,
                  float* noise_preds, int batch, void* workspace, int64_t workspace_bytes, llie_stream stream);
+
+int llie_graph_cache_entries(const llie_ctx* ctx);
 
 /* Byte-level I/O either side of the path (scripts/inference.py:99-134), on the device:
  *   llie_preprocess_u8:  uint8 HWC RGB [B][H0][W0][3] -> resize to SxS (cv2.INTER_LINEAR geometry, round half
@@ -256,6 +259,13 @@ int llie_film(const float* silu_temb, const float* wf, const float* bf, float* f
 int llie_gram_stats(int dtype, const void* x0, int c0, const void* x1, int c1, const float* scale, const float* bias, int batch,
                     int pixels, float* part, float* gtot, unsigned int* tickets, llie_stream stream);
 int64_t llie_gram_part_floats(int K, int pixels);
+/* The finalize behind it (gram.hip: gram_finalize_kernel; replaces nn.GroupNorm(32, 4K) statistics of h1 = W1 . relu6(norm1(x)),
+ * efficient_unet.py:174,212, + the FiLM fold :215-217): sum h1[c] = 6 w_c . m, sum h1[c]^2 = 36 w_c^T G w_c (row products and sums
+ * in fp64), then scale[b][c] = rstd gamma[c] (1 + fs), shift[b][c] = (beta[c] - mean rstd gamma[c]) (1 + fs) + fh like
+ * llie_groupnorm_finalize.  gram_totals: llie_gram_stats' gtot; w_expand: [4K][K] of the compute type; K in {32, 64, 96}. */
+int llie_gram_finalize(int dtype, const float* gram_totals, const void* w_expand, int K, int pixels, const float* gamma, const float* beta,
+                       const float* film, int64_t film_stride, float eps, float post_scale, int batch, float* scale_out, float* shift_out,
+                       llie_stream stream);
 int llie_dwconv3x3(int dtype, const void* in, void* out, const float* scale, const float* bias, const float* w9c,
                    float* pool, int B, int H, int W, int C, llie_stream stream);
 int llie_dwconv3x3_tiles(int H, int W);

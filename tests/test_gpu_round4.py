@@ -1,0 +1,135 @@
+"""GPU tests added in round 4 (through the C ABI).
+
+  * llie_gram_finalize (gram.hip: gram_finalize_kernel) against a float64 restatement of GroupNorm-2 + FiLM over h1 = 6 W1 a',
+    including an ill-conditioned case (a' with a large mean and a small variance, weight rows that sum to ~0)
+  * launch-policy knobs that must never change a bit: the cache policy of the big tensors' stores ("nt_mask" / "nt_min_mb"),
+    expand_dw's grid ("irbx_grid*"): whole network, every compute dtype of the 2-byte engines
+  * the hipGraph cache of llie_enhance is bounded (least recently used entry evicted) and an evicted key still gives its bits
+"""
+import importlib
+import math
+
+import pytest
+import torch
+
+import oracle
+from conftest import synth_input
+
+pytestmark = pytest.mark.gpu
+M = importlib.import_module("cv-diffusion-model_amd")
+N = importlib.import_module("cv-diffusion-model_amd._native")
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+# ------------------------------------------------------------------ gram_finalize
+def _gram_case(K, P, B, tdt, hard, seed):
+    g = torch.Generator().manual_seed(seed)
+    if hard:  # nearly constant activations near the clamp's upper end, expand rows with (almost) zero sum
+        a = (0.9 + 0.02 * torch.randn(B, P, K, generator=g)).clamp(0, 1)
+        w = torch.randn(4 * K, K, generator=g) / math.sqrt(K)
+        w = w - w.mean(1, keepdim=True) * 0.98
+    else:
+        a = torch.rand(B, P, K, generator=g).clamp(0, 1) * (torch.rand(B, 1, K, generator=g) + 0.2)
+        w = torch.randn(4 * K, K, generator=g) / math.sqrt(K)
+    return a.to(tdt), w.to(tdt)
+
+
+@pytest.mark.parametrize("dtype,tdt", [(1, torch.float16), (2, torch.bfloat16)])
+@pytest.mark.parametrize("K,P,hard", [(32, 4096, False), (64, 2048, False), (96, 8192, False), (32, 65536, True), (96, 16384, True)])
+def test_gram_finalize_entry_point_vs_float64(dev, dtype, tdt, K, P, hard):
+    """scale / shift of norm2 + FiLM (efficient_unet.py:212-217) from (G, m): against float64 statistics of h1 = 6 W a' taken
+    over the pixels themselves.  G and m are handed over in fp32 as llie_gram_stats leaves them (rounded from float64 here), so
+    the bound covers the finalize and the fp32 storage of G -- in the ill-conditioned case that storage dominates: the
+    variance is recovered from a quadratic form whose terms are ~1e4 times larger than the result."""
+    L = N.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    B, C = 2, 4 * K
+    a, w = _gram_case(K, P, B, tdt, hard, seed=K + P)
+    ad, wd = a.double(), w.double()
+    G = torch.einsum("bpi,bpj->bij", ad, ad)
+    m = ad.sum(1)
+    gtot = torch.cat([G.reshape(B, K * K), m], 1).float().contiguous().to(dev)
+    g = torch.Generator().manual_seed(7)
+    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.2
+    fl = torch.randn(B, 2 * C, generator=g) * 0.3
+    sc, sh = torch.empty(B, C, device=dev), torch.empty(B, C, device=dev)
+    wdev, gd, bd, fd = w.to(dev), gamma.to(dev), beta.to(dev), fl.to(dev)
+    N.check(L.llie_gram_finalize(dtype, gtot.data_ptr(), wdev.data_ptr(), K, P, gd.data_ptr(), bd.data_ptr(), fd.data_ptr(), 2 * C, 1e-5, 0.0,
+                                 B, sc.data_ptr(), sh.data_ptr(), st), "gram_finalize")
+    torch.cuda.synchronize()
+    h = 6.0 * torch.einsum("bpk,ck->bpc", ad, wd)                      # [B][P][C]
+    hg = h.view(B, P, 32, C // 32)
+    mean = hg.mean((1, 3))
+    var = (hg * hg).mean((1, 3)) - mean * mean
+    rstd = 1.0 / torch.sqrt(var.clamp_min(0) + 1e-5)
+    mean_c, rstd_c = mean.repeat_interleave(C // 32, 1), rstd.repeat_interleave(C // 32, 1)
+    fs, fh = 1.0 + fl[:, :C].double(), fl[:, C:].double()
+    sc_ref = rstd_c * gamma.double() * fs
+    sh_ref = (beta.double() - mean_c * rstd_c * gamma.double()) * fs + fh
+    # judged on what the consumer computes: the normalised tensor h * scale + shift
+    got = h * sc.cpu().double()[:, None, :] + sh.cpu().double()[:, None, :]
+    ref = h * sc_ref[:, None, :] + sh_ref[:, None, :]
+    err = (got - ref).abs().max().item()
+    assert err < (2e-3 if hard else 2e-5), err
+
+
+# ------------------------------------------------------------------ launch-policy knobs never change a bit
+@pytest.mark.parametrize("cd", ["fp16", "bf16"])
+def test_store_policy_and_grid_knobs_do_not_change_a_bit(dev, cd):
+    """small@128, B=3: non-temporal stores for every producer and every tensor size (nt_mask = 31, nt_min_mb = 1), none at all,
+    and three expand_dw grid choices all give the default build's bits."""
+    L = N.lib()
+    spec = oracle.make_spec("small", 128)
+    sd = oracle.synth_state_dict(oracle.param_shapes(spec))
+    m = M.LowLightDiffusion(unet_variant="small", image_size=128, num_inference_steps=4, compute_dtype=cd)
+    m.load_state_dict(sd)
+    m = m.to(dev).eval()
+    low = synth_input("r4:low128", (3, 3, 128, 128), -1.0, -0.4).to(dev)
+    noise = torch.stack(oracle.draw_noise(3, 128, 4, seed=31)).to(dev)
+    base = m.enhance(low, 4, noise=noise).cpu()
+    settings = [{"nt_mask": 31, "nt_min_mb": 1}, {"nt_mask": 0}, {"irbx_grid": 96}, {"irbx_grid2": 7, "irbx_grid4": 1000, "irbx_grid6": 48}]
+    defaults = {"nt_mask": 1, "nt_min_mb": 100, "irbx_grid": 0, "irbx_grid2": 0, "irbx_grid4": 0, "irbx_grid6": 0}
+    try:
+        for s in settings:
+            for k, v in s.items():
+                N.check(L.llie_tune(k.encode(), v))
+            for _ in range(2):  # eager, then the captured graph
+                out = m.enhance(low, 4, noise=noise).cpu()
+                assert torch.equal(out, base), s
+            for k in s:
+                N.check(L.llie_tune(k.encode(), defaults[k]))
+    finally:
+        for k, v in defaults.items():
+            L.llie_tune(k.encode(), v)
+
+
+# ------------------------------------------------------------------ bounded hipGraph cache
+def test_graph_cache_is_bounded_and_evicted_keys_still_work(dev):
+    """20 different (batch, steps) keys on one model: at most 16 captured graphs stay alive, and the first key -- evicted by
+    then -- reproduces its first result bit for bit when it comes back (eager, captured again, replayed)."""
+    L = N.lib()
+    m = M.LowLightDiffusion(unet_variant="small", image_size=64, num_inference_steps=4, compute_dtype="fp16").to(dev).eval()
+    low = synth_input("r4:low64", (5, 3, 64, 64), -1.0, -0.4).to(dev)
+    noise = torch.stack(oracle.draw_noise(5, 64, 4, seed=3)).to(dev)
+    keys = [(b, n) for n in (4, 3, 2, 1) for b in (1, 2, 3, 4, 5)]
+    first = {}
+    h = None
+    for b, n in keys:
+        for rep in range(3):  # eager, capture, replay
+            out = m.enhance(low[:b], n, noise=noise[:n, :b]).cpu()
+            if rep == 0:
+                first[(b, n)] = out
+            else:
+                assert torch.equal(out, first[(b, n)]), (b, n, rep)
+        h = m.unet._prepare(b, dev)[0]
+        assert 0 < L.llie_graph_cache_entries(h.h) <= 16
+    assert L.llie_graph_cache_entries(h.h) == 16
+    b, n = keys[0]
+    for rep in range(3):
+        assert torch.equal(m.enhance(low[:b], n, noise=noise[:n, :b]).cpu(), first[(b, n)]), rep
+    assert L.llie_graph_cache_entries(h.h) == 16

@@ -456,3 +456,17 @@ def test_parameter_list_follows_replaced_parameters():
     m2 = copy.deepcopy(m)
     assert all(a is b for a, b in zip(m2.unet._plist(), [dict(m2.unet.named_parameters())[k] for k in keys]))
     assert all(a is not b for a, b in zip(m2.unet._plist(), u._plist()))
+
+
+def test_groupnorm_finalize_rejects_bad_arguments_before_touching_the_device():
+    """llie_groupnorm_finalize is a public entry point: groups == 0 (a host division by zero in the launcher), non-positive pixel or
+    tile counts and a channel count that the groups do not divide come back as LLIE_ERR_ARG, never as a signal (round-3 advisor
+    finding).  No HIP call is made on these paths, so the check runs without a GPU; pointers are dummies that are never read."""
+    import ctypes as C
+    L = native.lib()
+    buf = (C.c_float * 64)()
+    p = C.cast(buf, C.c_void_p)
+    def call(ntiles0=1, ch0=32, groups=32, pixels=128, ntiles1=0, ch1=0, slab1=None):
+        return L.llie_groupnorm_finalize(p, ntiles0, ch0, slab1, ntiles1, ch1, groups, pixels, p, p, None, 0, 1e-5, 0.0, 1, p, p, None)
+    for kw in (dict(groups=0), dict(groups=-4), dict(pixels=0), dict(ntiles0=0), dict(ch0=48), dict(slab1=p, ch1=32, ntiles1=0), dict(ch0=0)):
+        assert call(**kw) < 0, kw
