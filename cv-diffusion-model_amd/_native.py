@@ -25,7 +25,7 @@ EXPORTS = [
     "llie_profile_begin", "llie_profile_end", "llie_enhance_workspace_bytes",
     "llie_preprocess_u8", "llie_postprocess_u8", "llie_profile_report", "llie_pw_gemm", "llie_pw_gemm_tile_rows", "llie_dwconv3x3", "llie_dwconv3x3_tiles", "llie_tune",
     "llie_grad_numel", "llie_param_grad_offset", "llie_train_workspace_bytes", "llie_unet_train_forward",
-    "llie_unet_backward", "llie_module_backward", "llie_load_all", "llie_profile_dump", "llie_copy_probe", "llie_rw_probe", "llie_pw_expand", "llie_gram_stats", "llie_gram_part_floats", "llie_groupnorm_finalize", "llie_conv3x3", "llie_conv3x3_tiles", "llie_linattn", "llie_linattn_splits", "llie_se_mlp", "llie_film", "llie_refresh_params", "llie_path_bytes", "llie_time_embed", "llie_debug_irbx_stamps", "llie_debug_gemm_stamps", "llie_debug_pwx_stamps", "llie_graph_cache_entries", "llie_gram_finalize",
+    "llie_unet_backward", "llie_module_backward", "llie_load_all", "llie_profile_dump", "llie_copy_probe", "llie_rw_probe", "llie_pw_expand", "llie_gram_stats", "llie_gram_part_floats", "llie_groupnorm_finalize", "llie_conv3x3", "llie_conv3x3_tiles", "llie_linattn", "llie_linattn_splits", "llie_se_mlp", "llie_film", "llie_refresh_params", "llie_path_bytes", "llie_time_embed", "llie_debug_irbx_stamps", "llie_debug_gemm_stamps", "llie_debug_pwx_stamps", "llie_graph_cache_entries", "llie_debug_conv_stamps", "llie_gram_finalize",
 ]
 K_GEMM, K_DW, K_CONV3, K_SE, K_OTHER = 1, 2, 4, 8, 16
 
@@ -123,6 +123,7 @@ def lib() -> C.CDLL:
     L.llie_graph_cache_entries.argtypes = [C.c_void_p]
     L.llie_graph_cache_entries.restype = C.c_int
     L.llie_debug_gemm_stamps.argtypes = [C.POINTER(C.c_double)]
+    L.llie_debug_conv_stamps.argtypes = [C.POINTER(C.c_double)]
     L.llie_grad_numel.argtypes = [vp]
     L.llie_grad_numel.restype = i64
     L.llie_param_grad_offset.argtypes = [vp, ci]

@@ -8,6 +8,7 @@
 //               halo patch is interpolated on the fly into LDS, so the 4x tensor never reaches HBM.
 #include <string>
 #include <type_traits>
+#include <vector>
 
 #include "common.h"
 #include "kernels.h"
@@ -426,9 +427,23 @@ hipError_t launch_final_conv(int dtype, const FinalConvArgs& a, hipStream_t s) {
 // =============================================================================================
 // Implicit-GEMM 3x3 conv on MFMA.  MODE 0: stride 2, pad 1.  MODE 1: bilinear x2 (align_corners=False:
 // src = (dst+0.5)/2 - 0.5 clamped at 0, upper neighbour clamped at n-1) then stride 1, pad 1.
-template <typename T, int MODE, int TW, int BN, int WM, int WN, bool RAGGED = false>
+// STAMP: diagnostic build (llie_tune("conv_stamp", 1)): s_memtime sums per wave into a.stamps[wave][kConvStamps] = {0 patch
+// commit (bounds / bilinear blend + ds_write), 1 first W tile staged + barrier, 2 operand ds_reads of a tap, 3 its MFMAs,
+// 4 next W tile staged + prefetch issued, 5 the tap's barrier, 6 epilogue}; never used in production.
+constexpr int kConvStamps = 7;
+template <typename T, int MODE, int TW, int BN, int WM, int WN, bool RAGGED = false, bool STAMP = false>
 __global__ void __launch_bounds__(WM* WN * 64) conv3x3_kernel(const Conv3Args a) {
   constexpr int NT = WM * WN * 64;
+  unsigned long long tk[kConvStamps] = {}, t_prev = 0;
+  auto stamp = [&](int slot) {
+    if constexpr (STAMP) {
+      __builtin_amdgcn_sched_barrier(0);
+      const unsigned long long now = __builtin_amdgcn_s_memtime();
+      __builtin_amdgcn_sched_barrier(0);
+      if (slot >= 0) tk[slot] += now - t_prev;
+      t_prev = now;
+    }
+  };
   constexpr int TH = 8, BM = TH * TW;
   constexpr int VEC = Elem<T>::VEC, VPR = 32 / VEC, PITCH = TilePitch<T>::value;
   constexpr int MI = BM / (WM * 32), NI = BN / (WN * 32);
@@ -584,6 +599,7 @@ __global__ void __launch_bounds__(WM* WN * 64) conv3x3_kernel(const Conv3Args a)
     for (int it = 0; it < P_ITEMS; ++it) issue_item(it, c0);
   };
   if (PREF) issue_patch(0);
+  stamp(-1);
   for (int c0 = 0; c0 < a.Cin; c0 += 32) {
     prefetch_w(0, c0);
     if constexpr (PREF) {  // this chunk's patch: its loads were issued during the previous chunk's taps
@@ -619,10 +635,12 @@ __global__ void __launch_bounds__(WM* WN * 64) conv3x3_kernel(const Conv3Args a)
         st_vec<T>(sP + pix * PITCH + kv, v);
       }
     }
+    stamp(0);
     stage_w(0);
     prefetch_w(1, c0);
     wg_barrier();  // patch and W tile of tap 0 visible
     if (PREF && c0 + 32 < a.Cin) issue_patch(c0 + 32);
+    stamp(1);
     for (int tap = 0; tap < 9; ++tap) {
       const int toff = ((tap / 3) * PW + (tap % 3)) * PITCH;
       T fa[MI][16], fb[NI][16];
@@ -638,15 +656,25 @@ __global__ void __launch_bounds__(WM* WN * 64) conv3x3_kernel(const Conv3Args a)
 #pragma unroll
         for (int q = 0; q < 16 / VEC; ++q) *reinterpret_cast<vec_t*>(&fb[j][q * VEC]) = *reinterpret_cast<const vec_t*>(p + q * VEC);
       }
+      if constexpr (STAMP) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      stamp(2);
 #pragma unroll
       for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < NI; ++j) Mfma<T>::chunk(fa[i], fb[j], acc[i][j]);
+      stamp(3);
       if (tap + 1 < 9) {
         stage_w((tap + 1) & 1);  // its last readers finished before the previous barrier
         if (tap + 2 < 9) prefetch_w(tap + 2, c0);
       }
+      stamp(4);
       wg_barrier();  // next W tile visible; everyone done with this one (and, after tap 8, with the patch)
+      stamp(5);
+      // (Tried in round 4 and removed: issuing the next tap's operand ds_reads right behind this tap's MFMAs, into the same
+      // registers, with a third W buffer -- MFMAs issue in order at the pipe's pace, so the reads start when the last MFMA
+      // has issued, and the in-place overwrite of MFMA source registers stalls: 313 vs 244 us at C = 256.  A second
+      // register set costs 32 VGPRs = one of the two waves per SIMD.  The loop is co-bound by LDS traffic: per tap and
+      // workgroup 32 KB of fragment reads (128 cycles) + 8 KB of W tile writes (~104) against 256 cycles of MFMA.)
     }
   }
 
@@ -721,6 +749,28 @@ __global__ void __launch_bounds__(WM* WN * 64) conv3x3_kernel(const Conv3Args a)
       a.stats[((size_t)(b * tiles + tile) * 2 + which) * a.Cout + n0 + c] = t;
     }
   }
+  stamp(6);
+  if constexpr (STAMP) {
+    if (a.stamps && lane == 0) {
+#pragma unroll
+      for (int i = 0; i < kConvStamps; ++i) a.stamps[((size_t)blockIdx.x * (NT / 64) + wave) * kConvStamps + i] = tk[i];
+    }
+  }
+}
+
+static int g_conv_stamp = 0;
+static unsigned long long* g_conv_stamps = nullptr;
+static size_t g_conv_stamp_n = 0;
+void conv3x3_stamp(int v) { g_conv_stamp = v; }
+hipError_t conv3x3_stamp_fetch(double* out8) {  // mean cycles per wave of the last stamped launch (kConvStamps slots), then the wave count
+  if (!g_conv_stamps || !g_conv_stamp_n) return hipErrorInvalidValue;
+  std::vector<unsigned long long> h(g_conv_stamp_n);
+  if (hipError_t e = hipMemcpy(h.data(), g_conv_stamps, h.size() * 8, hipMemcpyDeviceToHost); e != hipSuccess) return e;
+  for (int i = 0; i < kConvStamps; ++i) out8[i] = 0.0;
+  for (size_t i = 0; i < h.size(); ++i) out8[i % kConvStamps] += (double)h[i];
+  for (int i = 0; i < kConvStamps; ++i) out8[i] /= (double)(h.size() / kConvStamps);
+  out8[kConvStamps] = (double)(h.size() / kConvStamps);
+  return hipSuccess;
 }
 
 static int conv_tw(int Wo) { return (Wo % 16 == 0) ? 16 : 8; }
@@ -745,6 +795,22 @@ static hipError_t launch_conv_cfg(const Conv3Args& a, hipStream_t s) {
                                   std::to_string(TW) + ", " + std::to_string(BN) + ", " + std::to_string(WM) + ", " +
                                   std::to_string(WN) + ">";
   note_kernel(name.c_str());
+  if constexpr (MODE == 1 && TW == 16 && !RAGGED && std::is_same<T, half_t>::value) {
+    if (g_conv_stamp) {  // diagnostic build with in-kernel cycle stamps
+      const size_t n = (size_t)grid * (NT / 64) * kConvStamps;
+      if (n > g_conv_stamp_n || !g_conv_stamps) {
+        if (g_conv_stamps) (void)hipFree(g_conv_stamps);
+        if (hipError_t e = hipMalloc(reinterpret_cast<void**>(&g_conv_stamps), n * 8); e != hipSuccess) return e;
+      }
+      g_conv_stamp_n = n;
+      Conv3Args b = a;
+      b.stamps = g_conv_stamps;
+      if (hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_kernel<T, MODE, TW, BN, WM, WN, RAGGED, true>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); e != hipSuccess) return e;
+      hipLaunchKernelGGL((conv3x3_kernel<T, MODE, TW, BN, WM, WN, RAGGED, true>), dim3(grid), dim3(NT), lds, s, b);
+      return hipGetLastError();
+    }
+  }
   hipLaunchKernelGGL((conv3x3_kernel<T, MODE, TW, BN, WM, WN, RAGGED>), dim3(grid), dim3(NT), lds, s, a);
   return hipGetLastError();
 }

@@ -2370,6 +2370,7 @@ int llie_tune(const char* knob, int value) {
   if (!strcmp(knob, "irbx_grid4")) { irbx_grid(4, value); return LLIE_OK; }
   if (!strcmp(knob, "irbx_grid6")) { irbx_grid(6, value); return LLIE_OK; }
   if (!strcmp(knob, "irbx_var")) { irbx_var(value); return LLIE_OK; }
+  if (!strcmp(knob, "conv_stamp")) { conv3x3_stamp(value); return LLIE_OK; }
   if (!strcmp(knob, "gemm_stamp")) { pw_gemm_stamp(value); return LLIE_OK; }
   if (!strcmp(knob, "pwx")) { pw_expand_enable(value); return LLIE_OK; }
   if (!strcmp(knob, "pwx_ablate")) { pw_expand_debug(value, -1); return LLIE_OK; }
@@ -2394,6 +2395,14 @@ int llie_debug_pwx_stamps(double* out4) {
   if (!out4) return LLIE_ERR_ARG;
   hipError_t e = hipDeviceSynchronize();
   if (e == hipSuccess) e = pw_expand_stamp_fetch(out4);
+  return e == hipSuccess ? LLIE_OK : LLIE_ERR_ARG;
+}
+
+// diagnostic: mean per-wave cycles of the last stamped up-sampling conv launch (llie_tune("conv_stamp", 1)); synchronises
+int llie_debug_conv_stamps(double* out8) {
+  if (!out8) return LLIE_ERR_ARG;
+  hipError_t e = hipDeviceSynchronize();
+  if (e == hipSuccess) e = conv3x3_stamp_fetch(out8);
   return e == hipSuccess ? LLIE_OK : LLIE_ERR_ARG;
 }
 

@@ -268,7 +268,10 @@ struct Conv3Args {
   int B, Hi, Wi, Cin, Cout;
   int mode;
   int nt;              // 1: non-temporal output stores (see GemmArgs::nt)
+  unsigned long long* stamps;  // diagnostic builds only (conv3x3_stamp)
 };
+void conv3x3_stamp(int v);
+hipError_t conv3x3_stamp_fetch(double* out8);  // 7 per-wave cycle sums (conv.hip: STAMP) + waves averaged
 hipError_t launch_conv3x3(int dtype, const Conv3Args& a, hipStream_t s);
 int conv3x3_ntiles(int Ho, int Wo);
 

@@ -288,11 +288,12 @@ int llie_rw_probe(const void* src, void* dst, int64_t units, int reads, int writ
  *   "gram" [1] (norm2 statistics of the recompute form from the Gram matrix of the block input, gram.hip; 0 = expand_stats),
  *   "pwx_nbw" [0 = per-K default] (32-channel blocks per weight buffer), "pwx_ablate" 6 / 7 (stores straight from registers / through the LDS tile)
  * Diagnostics whose results are WRONG or slow (timing studies only): "skip_small", "gemm_ablate", "dw_ablate",
- * "irbx_ablate", "gemm_stamp", "irbx_stamp", "pwx_ablate", "pwx_stamp".
+ * "irbx_ablate", "gemm_stamp", "irbx_stamp", "conv_stamp", "pwx_ablate", "pwx_stamp".
  * Threading: the knobs are plain process-wide variables read by every forward; call llie_tune only while no other
  * thread is inside an llie_* compute call (same rule as the handle itself: SURVEY.md 8b, one stream at a time). */
 int llie_tune(const char* knob, int value);
 int llie_debug_irbx_stamps(double* out10); /* diagnostic builds: 9 per-wave cycle sums of expand_dw (irbx.hip: STAMP) + waves averaged */
+int llie_debug_conv_stamps(double* out8); /* diagnostic builds: 7 per-wave cycle sums of the up-sampling conv (conv.hip: STAMP) + waves averaged */
 int llie_debug_gemm_stamps(double* out3); /* diagnostic builds: see gemm.hip (STAMP) */
 int llie_debug_pwx_stamps(double* out4);  /* diagnostic builds: see pwx.hip (STAMP): {A phase, channel loop, of which waiting for the weight DMA} cycles per wave, waves */
 
