@@ -111,6 +111,12 @@ __device__ __forceinline__ void fma_mix_hi(float& acc, uint32_t w2, uint32_t f2)
 }
 
 // ---------------------------------------------------------------------------------------------
+// Tile index of workgroup `bid` of a 1-D run of `n` spatial tiles so that each XCD (workgroups are dealt to the eight XCDs
+// round-robin, one L2 each) owns a run of n / 8 CONSECUTIVE tiles: neighbours then share halo lines in one L2.  Identity when
+// n is not a multiple of 8.  A permutation of [0, n): every tile is still computed exactly once.
+__device__ __forceinline__ int xcd_tile_order(int bid, int n) { return (n & 7) ? bid : (bid & 7) * (n >> 3) + (bid >> 3); }
+
+// ---------------------------------------------------------------------------------------------
 // Workgroup barrier that first drains this wave's outstanding LDS operations.  __syncthreads() alone is not enough on
 // gfx950: the target has back-off barriers, so hipcc does not place an s_waitcnt in front of s_barrier by itself, and its
 // memory model treats LDS as totally ordered across the waves of a workgroup -- a ds_write issued just before the

@@ -104,7 +104,11 @@ __global__ void __launch_bounds__(256) init_conv_mfma_kernel(const InitConvArgs 
   __shared__ float red[4][2][32];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int tiles_x = (a.W + TW - 1) / TW;  // the last tile of a row may be partly empty (W % 32 != 0)
-  const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x, b = blockIdx.y;
+  // XCD-aware tile order (workgroups are dealt round-robin to the 8 XCDs, one L2 each): an XCD gets a run of consecutive tiles,
+  // so horizontal neighbours share the lines their halo columns straddle in ONE L2.  With neighbours on different XCDs every
+  // 136-byte patch row cost three 128-byte lines per XCD: 275 MB of HBM traffic per launch against 184.5 MB algorithmic.
+  const int tile_id = xcd_tile_order(blockIdx.x, gridDim.x);
+  const int tx = tile_id % tiles_x, ty = tile_id / tiles_x, b = blockIdx.y;
   const int x0 = tx * TW, y0 = ty * TH;
   const int Cin = a.c0 + a.c1;
   const size_t plane = (size_t)a.H * a.W;
@@ -194,7 +198,7 @@ __global__ void __launch_bounds__(256) init_conv_mfma_kernel(const InitConvArgs 
       if (tid < 64) {
         const int which = tid >> 5, o = tid & 31;
         const float tt = red[0][which][o] + red[1][which][o] + red[2][which][o] + red[3][which][o];
-        a.stats[((size_t)(b * ntiles + blockIdx.x) * 2 + which) * a.Cout + oc0 + o] = tt;
+        a.stats[((size_t)(b * ntiles + tile_id) * 2 + which) * a.Cout + oc0 + o] = tt;
       }
       wg_barrier();
     }
@@ -284,7 +288,7 @@ __global__ void __launch_bounds__(256) final_conv_kernel(const FinalConvArgs a) 
 // K order per 32-channel chunk: k-step = (tap, 16-channel half); lane half h takes 8 channels.
 // Weights pre-packed as [chunk][18][2][4][8] T (output channel padded to 4).
 template <typename T, int TW>
-__global__ void __launch_bounds__(256) final_conv_mfma_kernel(const FinalConvArgs a) {
+__global__ void __launch_bounds__(256, 4) final_conv_mfma_kernel(const FinalConvArgs a) {
   typedef typename Elem<T>::vec_t vec_t;
   // output tile (256 / TW) x TW pixels.  TW = 16 is used: 8 x 32 tiles (128-byte instead of 64-byte runs on the fp32 planes
   // of the scheduler step) measured 210 us against 163 us at B = 32 -- this kernel is not bound by its coalescing
@@ -292,7 +296,8 @@ __global__ void __launch_bounds__(256) final_conv_mfma_kernel(const FinalConvArg
   __shared__ __align__(16) T patch[(PH * PWD + 1) * PIX];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int tiles_x = (a.W + TW - 1) / TW;  // edge tiles may be partly empty
-  const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x, b = blockIdx.y;
+  const int tile_id = xcd_tile_order(blockIdx.x, gridDim.x);  // horizontal neighbours on one XCD (see init_conv_mfma_kernel)
+  const int tx = tile_id % tiles_x, ty = tile_id / tiles_x, b = blockIdx.y;
   const int x0 = tx * TW, y0 = ty * TH;
   const T* in = reinterpret_cast<const T*>(a.in) + (size_t)b * a.H * a.W * a.C;
   const T* wp = reinterpret_cast<const T*>(a.wp);
@@ -326,12 +331,24 @@ __global__ void __launch_bounds__(256) final_conv_mfma_kernel(const FinalConvArg
       }
     }
   }
-  vec_t wf[18];
-#pragma unroll
-  for (int ks = 0; ks < 18; ++ks) wf[ks] = r < 4 ? ld_vec<T>(wp + (((size_t)ks * 2 + h) * 4 + r) * 8) : zero;
+  // A operand = the weights: rows r < 4 of every fragment, zero elsewhere.  They used to live in 72 registers per lane
+  // (18 k-steps x 16 bytes), which held the kernel at two waves per SIMD -- a streaming kernel that waits on its patch loads;
+  // now the 2.3 KB of real rows per 32-channel chunk sit in LDS ([ks][h][4 rows][8 T], then one zero row) and each MFMA
+  // reads its fragment right before use (lanes with r >= 4 all read the zero row: a broadcast).
+  __shared__ __align__(16) T wsh[(18 * 2 * 4 + 1) * 8];
+  auto stage_wf = [&](int chunk) {
+    if (tid < 18 * 2 * 4) *reinterpret_cast<vec_t*>(wsh + tid * 8) = ld_vec<T>(wp + ((size_t)chunk * 18 * 2 * 4 + tid) * 8);
+    if (tid == 18 * 2 * 4) *reinterpret_cast<vec_t*>(wsh + tid * 8) = zero;
+  };
+  stage_wf(0);
+  const T* wrow = wsh + (r < 4 ? h * 4 + r : 18 * 2 * 4) * 8;  // + ks * 64 for rows r < 4
+  const int wstep = r < 4 ? 64 : 0;
 
   for (int cc = 0; cc < a.C; cc += 32) {
-    if (cc) wg_barrier();
+    if (cc) {
+      wg_barrier();  // everyone done with the previous chunk's patch and weights
+      stage_wf(cc >> 5);
+    }
     // stage the activated 10x34x32 patch (GroupNorm affine + SiLU applied once per element); a thread's
     // 8-channel slice is loop invariant (256 % 4 == 0), so its affine pairs live in registers
     const int cv = (tid & 3) * 8;
@@ -356,12 +373,6 @@ __global__ void __launch_bounds__(256) final_conv_mfma_kernel(const FinalConvArg
       *reinterpret_cast<vec_t*>(patch + pix * PIX + cv) = v;
     }
     wg_barrier();
-    // A operand: this lane's weight fragments (non-zero only for output channels r < 4); chunk 0's were fetched up front
-    if (cc) {
-#pragma unroll
-      for (int ks = 0; ks < 18; ++ks)
-        wf[ks] = r < 4 ? ld_vec<T>(wp + ((((size_t)(cc >> 5) * 18 + ks) * 2 + h) * 4 + r) * 8) : zero;
-    }
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       const int g = wave * 2 + t;
@@ -369,9 +380,12 @@ __global__ void __launch_bounds__(256) final_conv_mfma_kernel(const FinalConvArg
 #pragma unroll
       for (int ks = 0; ks < 18; ++ks) {
         const int tap = ks >> 1, q = ks & 1;
+        // one tap row (6 k-steps, 12 fragment reads) at a time: left alone, hipcc hoists all 36 reads of a block (144 registers)
+        if (ks % 6 == 0) __builtin_amdgcn_sched_barrier(0);
         const vec_t bv = *reinterpret_cast<const vec_t*>(patch + ((py + tap / 3) * PWD + px + tap % 3) * PIX + q * 16 + h * 8);
-        if constexpr (std::is_same<T, half_t>::value) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[ks], bv, acc[t], 0, 0, 0);
-        else acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks], bv, acc[t], 0, 0, 0);
+        const vec_t wv = *reinterpret_cast<const vec_t*>(wrow + ks * wstep);
+        if constexpr (std::is_same<T, half_t>::value) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wv, bv, acc[t], 0, 0, 0);
+        else acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wv, bv, acc[t], 0, 0, 0);
       }
     }
   }
