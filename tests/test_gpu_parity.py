@@ -424,7 +424,7 @@ def test_non_power_of_two_image_size_192(dev):
     assert max_abs(out.cpu(), oracle.enhance_ref(sd, spec, low, 4, noise)["enhanced"]) < 1e-3
 
 
-@pytest.mark.parametrize("variant,size,batch", [("base", 64, 2), ("tiny", 64, 2), ("base", 128, 1)])
+@pytest.mark.parametrize("variant,size,batch", [("base", 64, 2), ("tiny", 64, 2), ("base", 128, 1), ("tiny", 128, 1)])  # tiny@128 B=1 = BASELINE configs[0] on the HIP path
 def test_unpinned_variants_vs_oracle(dev, variant, size, batch):
     """tiny / base (opt-in, PARITY-UNPINNED: the reference cannot construct them, so no reference output exists; the
     oracle applies the same documented GroupNorm deviation, groups = largest divisor of C <= 32).  The engine pads
