@@ -554,6 +554,7 @@ int g_ztot = 1;  // SE pool as fixed-point totals + fused gate kernel (llie_tune
 // non-temporally by its producer (common.h: st_vec_pol).  g_nt_mask picks the producers: 1 expand_dw (h2), 2 pw_expand (h1),
 // 4 dwconv3x3 (h2), 8 project / attention GEMM outputs, 16 dense 3x3 conv outputs.  Values never change, only where lines live.
 int g_nt_min_mb = 100, g_nt_mask = 1;
+int g_se_mfma = 1;  // SE MLP of the wide blocks as two MFMA launches (small.hip: se_fc1_mfma / se_fc2_mfma); 0 = the row-parallel pair
 int g_skip_small = 0;  // timing ablation only (results are garbage): bit 0 no gn_finalize launches, bit 1 no SE launches
 int g_irbx_mask = 0x7;  // debug: which input widths may take the recompute form (bit 0: 32, bit 1: 64, bit 2: 96 channels)
 // Backward pass: run the weight-gradient kernels on a side stream next to the activation-gradient chain
@@ -791,6 +792,9 @@ struct Run {
     if (gram) rel(gtot); else rel(h1.slab);
     rel(as2); rel(ab2);
     // SE MLP
+    // (wide blocks of the 2-byte inference engines: fc1's pre-activations accumulate as integers in the zero-initialised region)
+    const bool sepre_ok = ztot && dt != LLIE_F32 && g_se_mfma && w.hid >= 768 && w.hid % 256 == 0 && w.sq % 64 == 0 && w.sq <= 512;
+    const size_t sepre = sepre_ok ? ztake((size_t)B * w.sq * 8) : 0;
     const size_t sehid = ar->alloc((size_t)B * w.sq * 4), gate = ar->alloc((size_t)B * w.hid * 4);
     const size_t semean = ar->alloc((size_t)B * w.hid * 4);
     if (!dry) {
@@ -799,7 +803,10 @@ struct Run {
       e.w1 = wptr(w.se_w1); e.b1 = wptr<float>(w.se_b1); e.w2 = wptr(w.se_w2); e.b2 = wptr<float>(w.se_b2);
       e.mean = p<float>(semean); e.hid = p<float>(sehid); e.gate = p<float>(gate); e.B = B; e.C = w.hid; e.Cs = w.sq;
       if (ztot) e.tot = p<unsigned long long>(ptot);
-      if (ztot && w.hid <= 384) {
+      if (sepre_ok) e.pre = p<long long>(sepre);
+      if (sepre_ok && g_se_mfma && se_mlp_mfma_supported(dt, e)) {
+        if (!(g_skip_small & 2)) timed(LLIE_K_SE, (int64_t)B * w.hid * 12 + 2LL * w.hid * w.sq * (int64_t)es(), [&] { return launch_se_mlp_mfma(dt, e, s); });
+      } else if (ztot && w.hid <= 384) {
         if (!(g_skip_small & 2)) timed(LLIE_K_SE, (int64_t)B * w.hid * 12 + 2LL * w.hid * w.sq * (int64_t)es(), [&] { return launch_se_gate(dt, e, s); });
       } else if (!(g_skip_small & 2)) timed(LLIE_K_SE, ((int64_t)B * dnt * w.hid * 4) + 2LL * w.hid * w.sq * (int64_t)es(), [&] {
         hipError_t r1 = launch_se_fc1(dt, e, s);
@@ -2354,6 +2361,7 @@ int llie_tune(const char* knob, int value) {
   if (!strcmp(knob, "gemm_bk")) { pw_gemm_force_bk(value); return LLIE_OK; }
   if (!strcmp(knob, "gemm_bk128")) { pw_gemm_bk128(value); return LLIE_OK; }
   if (!strcmp(knob, "skip_small")) { g_skip_small = value; return LLIE_OK; }
+  if (!strcmp(knob, "se_mfma")) { g_se_mfma = value; return LLIE_OK; }
   if (!strcmp(knob, "nt_min_mb")) { g_nt_min_mb = value; return LLIE_OK; }
   if (!strcmp(knob, "nt_mask")) { g_nt_mask = value; return LLIE_OK; }
   if (!strcmp(knob, "ztot")) { g_ztot = value; return LLIE_OK; }

@@ -203,7 +203,11 @@ struct SeArgs {
   float* gate;                      // [B][C]
   int B, C, Cs;
   const unsigned long long* tot;    // launch_se_gate: [B][C] fixed-point pool totals (kPoolFixScale)
+  long long* pre;                   // launch_se_mlp_mfma: [B][Cs] 2^-32 fixed-point fc1 pre-activations, zero at launch
 };
+// wide blocks, 2-byte T: fc1 and fc2 as two MFMA launches with the batch as the rows of a 32 x 32 tile (small.hip)
+bool se_mlp_mfma_supported(int dtype, const SeArgs& a);
+hipError_t launch_se_mlp_mfma(int dtype, const SeArgs& a, hipStream_t s);
 constexpr float kPoolFixScale = 16777216.f;  // 2^24: per-tile pool partials are rounded to 2^-24 before the integer add
 hipError_t launch_se_gate(int dtype, const SeArgs& a, hipStream_t s);  // mean -> fc1 -> ReLU6 -> fc2 -> sigmoid, one launch
 hipError_t launch_se_fc1(int dtype, const SeArgs& a, hipStream_t s);

@@ -361,6 +361,139 @@ __global__ void __launch_bounds__(1024) se_gate_kernel(const SeArgs a) {
     a.gate[(size_t)b * a.C + c] = sigmoidf(acc + a.b2[c]);
   }
 }
+// SE MLP of the wide blocks (more than 384 hidden channels) on the matrix pipe, 2-byte T: the batch is the 32 rows of one
+// 32x32x16 tile.  The row-parallel pair above re-stages the means in every one of its 500+ workgroups and spends two
+// dependent launches of 10-25 us on ~1 MFLOP per image; here
+//   fc1: grid (Cs / 32 column blocks, K slices): a wave turns its slice of the fixed-point pool totals into fp16 means in
+//        registers (its A fragments), loads its W1 fragments straight from HBM / L2 (the [Cs][C] rows ARE B fragments), runs
+//        4 MFMAs and adds its 32 x 32 partial products as 2^-32 fixed-point 64-bit integers into pre[B][Cs] (zero at launch;
+//        integer adds commute: bitwise reproducible, and a row = an image, so batch-invariant);
+//   fc2: grid (C / 32): A = relu6(pre + b1) rebuilt per wave slice of Cs, B = W2 rows, the four waves' partial tiles summed in
+//        wave order through LDS, sigmoid, gate.
+// Every global operand of a wave is requested before the first is used: one memory round trip per launch.
+constexpr float kSePreScale = 4294967296.f;  // 2^32
+template <typename T>
+__global__ void __launch_bounds__(256) se_fc1_mfma_kernel(const SeArgs a, const int kw /* K per wave */) {
+  static_assert(sizeof(T) == 2, "");
+  typedef typename Elem<T>::vec_t vec_t;
+  constexpr int MAXS = 4;  // k-steps per wave (launcher: kw <= 64)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 31, lh = lane >> 5;
+  const int n0 = blockIdx.x * 32, b0 = blockIdx.z * 32;
+  const int nb = a.B - b0 < 32 ? a.B - b0 : 32;
+  const int k0 = (blockIdx.y * 4 + wave) * kw + 8 * lh;
+  const int steps = kw >> 4;
+  const T* wrow = reinterpret_cast<const T*>(a.w1) + (size_t)(n0 + lr) * a.C + k0;
+  const unsigned long long* trow = a.tot + (size_t)(b0 + lr) * a.C + k0;
+  const bool live = lr < nb;
+  vec_t wf[MAXS];
+  u32x4 tq[MAXS][4];  // 8 totals of 8 bytes per step
+#pragma unroll
+  for (int s = 0; s < MAXS; ++s)
+    if (s < steps) {
+      wf[s] = ld_vec<T>(wrow + 16 * s);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) tq[s][q] = live ? *reinterpret_cast<const u32x4*>(trow + 16 * s + 2 * q) : u32x4{0u, 0u, 0u, 0u};
+    }
+  const float inv = 1.f / ((float)a.P * kPoolFixScale);
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+  for (int s = 0; s < MAXS; ++s)
+    if (s < steps) {
+      vec_t av;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const long long t0 = (long long)(((unsigned long long)tq[s][q][1] << 32) | tq[s][q][0]);
+        const long long t1 = (long long)(((unsigned long long)tq[s][q][3] << 32) | tq[s][q][2]);
+        av[2 * q] = (T)((float)t0 * inv);
+        av[2 * q + 1] = (T)((float)t1 * inv);
+      }
+      acc = mfma16<T>(av, wf[s], acc);
+    }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int b = mfma_row(r, lane);  // image of this accumulator register; column = lr
+    if (b < nb) atomicAdd(reinterpret_cast<unsigned long long*>(a.pre) + (size_t)(b0 + b) * a.Cs + n0 + lr, (unsigned long long)__float2ll_rn(acc[r] * kSePreScale));
+  }
+}
+template <typename T>
+__global__ void __launch_bounds__(256) se_fc2_mfma_kernel(const SeArgs a) {
+  static_assert(sizeof(T) == 2, "");
+  typedef typename Elem<T>::vec_t vec_t;
+  constexpr int MAXS = 8;  // k-steps per wave (launcher: Cs <= 512)
+  __shared__ float part[4][32 * 33];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 31, lh = lane >> 5;
+  const int n0 = blockIdx.x * 32, b0 = blockIdx.y * 32;
+  const int nb = a.B - b0 < 32 ? a.B - b0 : 32;
+  const int kw = a.Cs >> 2, steps = kw >> 4;
+  const int k0 = wave * kw + 8 * lh;
+  const T* wrow = reinterpret_cast<const T*>(a.w2) + (size_t)(n0 + lr) * a.Cs + k0;
+  const long long* prow = a.pre + (size_t)(b0 + lr) * a.Cs + k0;
+  const bool live = lr < nb;
+  vec_t wf[MAXS];
+  u32x4 pq[MAXS][4];
+  f32x4 bq[MAXS][2];
+#pragma unroll
+  for (int s = 0; s < MAXS; ++s)
+    if (s < steps) {
+      wf[s] = ld_vec<T>(wrow + 16 * s);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) pq[s][q] = live ? *reinterpret_cast<const u32x4*>(prow + 16 * s + 2 * q) : u32x4{0u, 0u, 0u, 0u};
+      bq[s][0] = *reinterpret_cast<const f32x4*>(a.b1 + k0 + 16 * s);
+      bq[s][1] = *reinterpret_cast<const f32x4*>(a.b1 + k0 + 16 * s + 4);
+    }
+  const float bc = a.b2[n0 + lr];
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  constexpr float unscale = 1.f / kSePreScale;
+#pragma unroll
+  for (int s = 0; s < MAXS; ++s)
+    if (s < steps) {
+      vec_t av;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const long long t0 = (long long)(((unsigned long long)pq[s][q][1] << 32) | pq[s][q][0]);
+        const long long t1 = (long long)(((unsigned long long)pq[s][q][3] << 32) | pq[s][q][2]);
+        const float h0 = live ? relu6f((float)t0 * unscale + bq[s][q >> 1][(2 * q) & 3]) : 0.f;
+        const float h1 = live ? relu6f((float)t1 * unscale + bq[s][q >> 1][(2 * q + 1) & 3]) : 0.f;
+        av[2 * q] = (T)h0;
+        av[2 * q + 1] = (T)h1;
+      }
+      acc = mfma16<T>(av, wf[s], acc);
+    }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) part[wave][mfma_row(r, lane) * 33 + lr] = acc[r];
+  wg_barrier();
+  for (int i = tid; i < 32 * 32; i += 256) {
+    const int b = i >> 5, n = i & 31;
+    if (b < nb) {
+      const float v = ((part[0][b * 33 + n] + part[1][b * 33 + n]) + part[2][b * 33 + n]) + part[3][b * 33 + n];
+      a.gate[(size_t)(b0 + b) * a.C + n0 + n] = sigmoidf(v + a.b2[n0 + n]);
+    }
+  }
+  (void)bc;
+}
+bool se_mlp_mfma_supported(int dtype, const SeArgs& a) {
+  if ((dtype != 1 && dtype != 2) || !a.tot || !a.pre || !a.gate || a.B <= 0 || a.P <= 0) return false;
+  return a.C % 256 == 0 && a.C >= 512 && a.Cs % 64 == 0 && a.Cs >= 64 && a.Cs <= 512;
+}
+hipError_t launch_se_mlp_mfma(int dtype, const SeArgs& a, hipStream_t s) {
+  if (!se_mlp_mfma_supported(dtype, a)) return hipErrorInvalidValue;
+  note_kernel("se_fc1_mfma_kernel+se_fc2_mfma_kernel");
+  const int ksl = a.C / 256, kw = 64;  // 256 channels of K per workgroup, 64 per wave (4 k-steps)
+  const dim3 g1(a.Cs / 32, ksl, (a.B + 31) / 32), g2(a.C / 32, (a.B + 31) / 32);
+  if (dtype == 1) {
+    hipLaunchKernelGGL(se_fc1_mfma_kernel<half_t>, g1, dim3(256), 0, s, a, kw);
+    hipLaunchKernelGGL(se_fc2_mfma_kernel<half_t>, g2, dim3(256), 0, s, a);
+  } else {
+    hipLaunchKernelGGL(se_fc1_mfma_kernel<bf16_t>, g1, dim3(256), 0, s, a, kw);
+    hipLaunchKernelGGL(se_fc2_mfma_kernel<bf16_t>, g2, dim3(256), 0, s, a);
+  }
+  return hipGetLastError();
+}
+
 hipError_t launch_se_gate(int dtype, const SeArgs& a, hipStream_t s) {
   if (!a.tot || !a.gate || a.C <= 0 || a.Cs <= 0 || a.P <= 0) return hipErrorInvalidValue;
   const int vec = dtype == 0 ? 4 : 8;

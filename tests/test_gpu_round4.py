@@ -133,3 +133,42 @@ def test_graph_cache_is_bounded_and_evicted_keys_still_work(dev):
     for rep in range(3):
         assert torch.equal(m.enhance(low[:b], n, noise=noise[:n, :b]).cpu(), first[(b, n)]), rep
     assert L.llie_graph_cache_entries(h.h) == 16
+
+
+# ------------------------------------------------------------------ SE MLP of the wide blocks on the matrix pipe
+def _irb_case(cin, cout, hw, b, name):
+    from oracle import unet_ref
+    from oracle.weightgen import synth_tensor
+    blk = M.InvertedResidualBlock(cin, cout, 128)
+    blk.load_state_dict({k: synth_tensor(name + "." + k, tuple(v.shape)) for k, v in blk.state_dict().items()})
+    sd = {name + "." + k: v.detach().clone() for k, v in blk.state_dict().items()}
+    x = synth_input(name + ".x", (b, cin, hw, hw), -2, 2)
+    te = synth_input(name + ".temb", (b, 128), -1, 1)
+    return blk, x, te, unet_ref.irb_forward(sd, name, x, te)
+
+
+@pytest.mark.parametrize("cd,tol", [("fp16", 6e-3), ("bf16", 5e-2)])
+@pytest.mark.parametrize("cin,cout,hw,b", [(256, 256, 16, 3), (512, 256, 8, 35), (192, 64, 16, 2), (384, 128, 16, 33)])
+def test_se_mlp_on_the_matrix_pipe(dev, cd, tol, cin, cout, hw, b):
+    """SqueezeExcitation (efficient_unet.py:96-100) of blocks with 768 ... 2048 hidden channels as two MFMA launches
+    (se_fc1_mfma / se_fc2_mfma: the batch is the rows of a 32 x 32 tile; batches of 33 / 35 need a second row block) against the
+    fp32 CPU oracle through the whole block, against the row-parallel pair it replaces (knob "se_mfma" = 0), and bitwise
+    independent of the batch: the first image alone gives the bits it has inside the batch."""
+    L = N.lib()
+    blk, x, te, ref = _irb_case(cin, cout, hw, b, f"r4se_{cin}_{cout}")
+    blk = blk.to(dev)
+    blk.compute_dtype = cd
+    scale = max(1.0, ref.abs().max().item())
+    try:
+        N.check(L.llie_tune(b"se_mfma", 1))
+        y1 = blk(x.to(dev), te.to(dev)).cpu()
+        one = blk(x[:1].to(dev), te[:1].to(dev)).cpu()
+        again = blk(x.to(dev), te.to(dev)).cpu()
+        N.check(L.llie_tune(b"se_mfma", 0))
+        y0 = blk(x.to(dev), te.to(dev)).cpu()
+    finally:
+        L.llie_tune(b"se_mfma", 1)
+    assert torch.isfinite(y1).all()
+    assert (y1 - ref).abs().max().item() < tol * scale, (y1 - ref).abs().max().item() / scale
+    assert (y1 - y0).abs().max().item() < tol * scale
+    assert torch.equal(one[0], y1[0]) and torch.equal(again, y1)
