@@ -6,7 +6,7 @@
 # 3. PMC passes in their own runs (--pmc only): FETCH_SIZE, WRITE_SIZE, SQ counters
 # 4. other configurations
 set -o pipefail
-O=${1:-gpurun_out/prof_r03}
+O=${1:-gpurun_out/prof_r04}
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 echo "== bench default"; python -u bench.py > $O/bench_fp16_b32.json 2> $O/bench_fp16_b32.err || exit 1
@@ -17,9 +17,11 @@ echo "== rocprof kernel trace"; rocprofv3 --kernel-trace --stats -d $O/kt -o kt 
 cp $(find $O/kt -name "*kernel_stats.csv" | head -1) $O/bench_fp16_b32_kernel_stats.csv; rm -rf $O/kt
 echo "== pmc fetch"; rocprofv3 --pmc FETCH_SIZE -d $O/pf -o pf --output-format csv -- python bench.py --no-cpu-baseline --no-roofline --steps 2 --warmup 1 > $O/pf.log 2>&1 || exit 1
 echo "== pmc write"; rocprofv3 --pmc WRITE_SIZE -d $O/pw -o pw --output-format csv -- python bench.py --no-cpu-baseline --no-roofline --steps 2 --warmup 1 > $O/pw.log 2>&1 || exit 1
-python tools/pmc_summary.py $O/pf $O/pw $O/pmc_traffic.json "round 3; python bench.py --no-cpu-baseline --no-roofline --steps 2 --warmup 1" > $O/pmc_traffic.txt 2>&1; rm -rf $O/pf $O/pw
+python tools/pmc_summary.py $O/pf $O/pw $O/pmc_traffic.json "round 4; python bench.py --no-cpu-baseline --no-roofline --steps 2 --warmup 1" > $O/pmc_traffic.txt 2>&1; rm -rf $O/pf $O/pw
 echo "== pmc sq"; rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -d $O/ps -o ps --output-format csv -- python bench.py --no-cpu-baseline --no-roofline --steps 2 --warmup 1 > $O/ps.log 2>&1 || exit 1
 python tools/pmc_sq_summary.py $O/ps $O/pmc_sq.json > $O/pmc_sq.txt 2>&1; rm -rf $O/ps
+echo "== pmc lds"; rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -d $O/pl -o pl --output-format csv -- python bench.py --no-cpu-baseline --no-roofline --steps 2 --warmup 1 > $O/pl.log 2>&1 || exit 1
+python tools/pmc_lds_summary.py $O/pl 30 > $O/pmc_lds.txt 2>&1; rm -rf $O/pl
 unset LLIE_ENHANCE_SPLIT
 echo "== other configurations"
 python -u bench.py --batch 1 --no-cpu-baseline > $O/bench_fp16_b1.json 2>> $O/other.err
