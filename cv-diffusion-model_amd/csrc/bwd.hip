@@ -133,20 +133,54 @@ hipError_t launch_batch_sum(const float* in, float* out, int B, int64_t stride, 
 //   dG = sum dz*xhat = rstd*(S2 - mean*S1),  dBc = S1,
 //   c1 = mean_group(G*dz) = sum_c G*S1/(cg*P),  c2 = mean_group(G*dz*xhat) = sum_c G*dG/(cg*P),
 //   dx = rstd*(G*dz - c1 - xhat*c2) = dz*(rstd*G) + x*(-rstd^2*c2) + (-rstd*c1 + mean*rstd^2*c2).
+// With a.slab set (round 4) the block first sums the producer's tile partials [B][ntiles][2][C] of its own cg channels -- what
+// slab_reduce_kernel did in a launch of its own, 47 times per training step on the critical chain -- in a fixed order: thread ->
+// (tile lane, channel), tile lanes combined in index order.
+constexpr int kGnCoefMaxCg = 64;
 __global__ void __launch_bounds__(256) gn_bwd_coef_kernel(const GnBwdArgs a) {
   __shared__ double part[2][4];
+  __shared__ float ssum[2][256];
+  __shared__ float sS[2][kGnCoefMaxCg];
   const int g = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int cg = a.C / a.groups, c_lo = g * cg;
   const float mean = a.mean[(size_t)b * a.groups + g], rstd = a.rstd[(size_t)b * a.groups + g];
   const float* S1 = a.S + (size_t)b * 2 * a.C;
   const float* S2 = S1 + a.C;
+  if (a.slab) {  // launcher: cg <= kGnCoefMaxCg
+    const int tln = 256 / cg, tl = tid / cg, ci = tid - tl * cg;  // tile lanes; threads beyond tln * cg idle
+    float p1 = 0.f, p2 = 0.f;
+    if (tl < tln) {
+      const float* ps = a.slab + (size_t)b * a.ntiles * 2 * a.C + c_lo + ci;
+      for (int t = tl; t < a.ntiles; t += tln) {
+        p1 += ps[(size_t)(2 * t) * a.C];
+        p2 += ps[(size_t)(2 * t + 1) * a.C];
+      }
+    }
+    ssum[0][tid] = p1;
+    ssum[1][tid] = p2;
+    wg_barrier();
+    if (tid < cg) {
+      float t1 = 0.f, t2 = 0.f;
+      for (int l = 0; l < tln; ++l) {
+        t1 += ssum[0][l * cg + tid];
+        t2 += ssum[1][l * cg + tid];
+      }
+      sS[0][tid] = t1;
+      sS[1][tid] = t2;
+    }
+    wg_barrier();
+  }
+  // S1 / S2 of channel c: from LDS (group-local index) when the partials were summed here, else from the [B][2][C] table
+  const bool local = a.slab != nullptr;
+  auto s1_of = [&](int c) { return local ? sS[0][c - c_lo] : S1[c]; };
+  auto s2_of = [&](int c) { return local ? sS[1][c - c_lo] : S2[c]; };
   const float* film = a.film ? a.film + (size_t)b * a.film_stride : nullptr;
   double t1 = 0.0, t2 = 0.0;
   for (int i = tid; i < cg; i += 256) {
     const int c = c_lo + i;
     const float G = a.gamma[c] * (film ? 1.f + film[c] : 1.f);
-    const float dG = rstd * (S2[c] - mean * S1[c]);
-    t1 += (double)G * (double)S1[c];
+    const float dG = rstd * (s2_of(c) - mean * s1_of(c));
+    t1 += (double)G * (double)s1_of(c);
     t2 += (double)G * (double)dG;
   }
   t1 = wave_sum(t1);
@@ -163,12 +197,13 @@ __global__ void __launch_bounds__(256) gn_bwd_coef_kernel(const GnBwdArgs a) {
     a.A[o] = rstd * G;
     a.Bq[o] = -rstd * rstd * c2;
     a.Cq[o] = -rstd * c1 + mean * rstd * rstd * c2;
-    a.dG[o] = rstd * (S2[c] - mean * S1[c]);
-    a.dBc[o] = S1[c];
+    a.dG[o] = rstd * (s2_of(c) - mean * s1_of(c));
+    a.dBc[o] = s1_of(c);
   }
 }
 hipError_t launch_gn_bwd_coef(const GnBwdArgs& a, hipStream_t s) {
   if (a.C % a.groups) return hipErrorInvalidValue;
+  if (a.slab ? (a.ntiles <= 0 || a.C / a.groups > kGnCoefMaxCg) : !a.S) return hipErrorInvalidValue;
   hipLaunchKernelGGL(gn_bwd_coef_kernel, dim3(a.groups, a.B), dim3(256), 0, s, a);
   return hipGetLastError();
 }

@@ -1212,9 +1212,14 @@ struct Back {
       m.as = p<float>(rec.as); m.ab = p<float>(rec.ab); m.act = act; m.dz = act == ACT_NONE ? nullptr : p(g);
       m.slab = p<float>(slab); m.M = M; m.C = C; m.P = P;
       if (!pre_tiles) chk(launch_bwd_mask_reduce(dt, m, s));
-      chk(launch_slab_reduce(p<float>(slab), p<float>(S), B, nt, 2, 2, C, s));
       GnBwdArgs a{};
-      a.S = p<float>(S); a.mean = p<float>(rec.mean); a.rstd = p<float>(rec.rstd); a.gamma = wptr<float>(gamma);
+      if (C / 32 <= 64) {  // the coefficient kernel sums the tile partials of its group itself (no slab_reduce launch)
+        a.slab = p<float>(slab); a.ntiles = nt;
+      } else {
+        chk(launch_slab_reduce(p<float>(slab), p<float>(S), B, nt, 2, 2, C, s));
+        a.S = p<float>(S);
+      }
+      a.mean = p<float>(rec.mean); a.rstd = p<float>(rec.rstd); a.gamma = wptr<float>(gamma);
       a.film = film; a.film_stride = fstride; a.C = C; a.groups = 32; a.P = P; a.B = B;
       a.A = p<float>(k.A); a.Bq = p<float>(k.Bq); a.Cq = p<float>(k.Cq); a.dG = p<float>(dG); a.dBc = p<float>(dBc);
       chk(launch_gn_bwd_coef(a, s));

@@ -378,6 +378,7 @@ hipError_t launch_batch_sum(const float* in, float* out, int B, int64_t stride, 
 //   dx = dz*A + x*Bq + Cq;  dG[b][c] = sum dz*xhat,  dBc[b][c] = sum dz  (before the FiLM / batch reductions)
 struct GnBwdArgs {
   const float* S; const float* mean; const float* rstd;   // [B][2][C], [B][groups], [B][groups]
+  const float* slab; int ntiles;                          // or (S null): the tile partials [B][ntiles][2][C], summed inside the kernel
   const float* gamma; const float* film; int64_t film_stride;  // FiLM rows of the forward (scale at c, shift at C+c) or null
   int C, groups, P, B;
   float* A; float* Bq; float* Cq; float* dG; float* dBc;   // [B][C] each
