@@ -145,9 +145,13 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[B
 
 // STAMP: diagnostic build (llie_tune("gemm_stamp", 1)): s_memtime per wave at kernel start / after the K loop / at the end,
 // summed into g.stamps[0..2] = {K loop, epilogue, waves}; never used in production.
-template <typename T, int BM, int BN, int WM, int WN, int BK, bool STAMP = false, bool RAGGED = false>
+// KTAIL (BK = 64 only): K = 64 n + 32 -- the last chunk's upper 32 columns do not exist and are staged as zeros (A and W), so the
+// 96 -> 32 project GEMM (K = 384 + 64 + 32) runs with 64-wide chunks like its 128 -> 32 sibling instead of 32-wide ones (half the
+// bytes per barrier: 4.4 instead of 5.6 TB/s).  The sequence of 32-wide k-steps per accumulator, hence every bit, is unchanged.
+template <typename T, int BM, int BN, int WM, int WN, int BK, bool STAMP = false, bool RAGGED = false, bool KTAIL = false>
 __global__ void __launch_bounds__(WM* WN * 64) pw_gemm_kernel(const GemmArgs g) {
   static_assert(!RAGGED || BM == 64, "ragged images use the 64-row tiles");
+  static_assert(!KTAIL || (BK == 64 && sizeof(T) == 2), "the half-empty last chunk exists for 64-wide chunks only");
   unsigned long long t_start = 0, t_loop = 0;
   if constexpr (STAMP) t_start = __builtin_amdgcn_s_memtime();
   constexpr int NT = WM * WN * 64;
@@ -204,16 +208,18 @@ __global__ void __launch_bounds__(WM* WN * 64) pw_gemm_kernel(const GemmArgs g) 
     const GemmSeg sg = g.seg[s];
     const int cl = k0 - (s == 0 ? 0 : (s == 1 ? koff1 : koff2));
     const T* abase = reinterpret_cast<const T*>(sg.ptr);
+    const bool kval = !KTAIL || k0 + kv < g.K;  // this thread's 16-byte column slice exists
 #pragma unroll
     for (int i = 0; i < A_PER; ++i) {
       const int idx = tid + i * NT;
       if (A_VECS % NT == 0 || idx < A_VECS) {
         int row = idx / VPR;
         if (RAGGED) row = row < vrows ? row : vrows - 1;  // rows past the image: re-read the last one (never stored or counted)
-        ra[i] = ld_vec<T>(abase + (size_t)(m0 + row) * sg.ch + cl + kv);
+        if (kval) ra[i] = ld_vec<T>(abase + (size_t)(m0 + row) * sg.ch + cl + kv);
+        else ra[i] = vec_t{};
       }
     }
-    r_aff = sg.as != nullptr;
+    r_aff = sg.as != nullptr && kval;
     r_act = sg.act;
     if (r_aff) {
       const float* ps = sg.as + (size_t)img * sg.aff_ld + cl + kv;
@@ -233,7 +239,8 @@ __global__ void __launch_bounds__(WM* WN * 64) pw_gemm_kernel(const GemmArgs g) 
       const int idx = tid + i * NT;
       if (B_VECS % NT == 0 || idx < B_VECS) {
         const int n = idx / VPR;
-        rb[i] = ld_vec<T>(wbase + (size_t)(n0 + n) * g.K + k0 + kv);
+        if (kval) rb[i] = ld_vec<T>(wbase + (size_t)(n0 + n) * g.K + k0 + kv);
+        else rb[i] = vec_t{};
       }
     }
   };
@@ -291,7 +298,7 @@ __global__ void __launch_bounds__(WM* WN * 64) pw_gemm_kernel(const GemmArgs g) 
     }
   };
 
-  const int nchunks = g.K / BK;
+  const int nchunks = (g.K + BK - 1) / BK;
   prefetch(0);
   for (int c = 0; c < nchunks; ++c) {
     if (!(g.dbg & 2) || c == 0) stage();  // dbg bit 1: timing ablation (no re-staging)
@@ -357,7 +364,7 @@ hipError_t pw_gemm_stamp_fetch(double* out3) {  // mean s_memtime ticks per wave
   return hipSuccess;
 }
 
-template <typename T, int BM, int BN, int WM, int WN, int BK, bool RAGGED = false>
+template <typename T, int BM, int BN, int WM, int WN, int BK, bool RAGGED = false, bool KTAIL = false>
 static hipError_t launch_cfg(const GemmArgs& a, hipStream_t s) {
   constexpr int NT = WM * WN * 64;
   constexpr int PITCH = BK + Elem<T>::VEC;
@@ -366,12 +373,12 @@ static hipError_t launch_cfg(const GemmArgs& a, hipStream_t s) {
   constexpr size_t lds = tiles > ctile ? tiles : ctile;
   static std::atomic<uint64_t> attr_done{0};
   if (lds > 48 * 1024) {
-    if (hipError_t e = ensure_max_lds(reinterpret_cast<const void*>(&pw_gemm_kernel<T, BM, BN, WM, WN, BK, false, RAGGED>), (int)lds, attr_done);
+    if (hipError_t e = ensure_max_lds(reinterpret_cast<const void*>(&pw_gemm_kernel<T, BM, BN, WM, WN, BK, false, RAGGED, KTAIL>), (int)lds, attr_done);
         e != hipSuccess)
       return e;
   }
   const unsigned grid = (unsigned)((a.M / a.P) * ((a.P + BM - 1) / BM) * (a.N / BN));  // == (M / BM) * (N / BN) unless RAGGED
-  if constexpr (sizeof(T) == 2 && BM == 128) {
+  if constexpr (sizeof(T) == 2 && BM == 128 && !KTAIL) {
     if (g_gemm_stamp) {
       if (hipError_t e = stamp_buffer((size_t)grid * (NT / 64)); e != hipSuccess) return e;
       GemmArgs b = a;
@@ -386,7 +393,7 @@ static hipError_t launch_cfg(const GemmArgs& a, hipStream_t s) {
                                   std::to_string(BN) + ", " + std::to_string(WM) + ", " + std::to_string(WN) + ", " +
                                   std::to_string(BK) + ">";
   note_kernel(name.c_str());
-  hipLaunchKernelGGL((pw_gemm_kernel<T, BM, BN, WM, WN, BK, false, RAGGED>), dim3(grid), dim3(NT), lds, s, a);
+  hipLaunchKernelGGL((pw_gemm_kernel<T, BM, BN, WM, WN, BK, false, RAGGED, KTAIL>), dim3(grid), dim3(NT), lds, s, a);
   return hipGetLastError();
 }
 
@@ -420,6 +427,13 @@ static hipError_t launch_t(const GemmArgs& a, hipStream_t s) {
   }
   if (BM == 128) {
     if (BN == 128) return k64 ? launch_cfg<T, 128, 128, 2, 2, 64>(a, s) : launch_cfg<T, 128, 128, 2, 2, 32>(a, s);
+    if constexpr (sizeof(T) == 2) {
+      // K = 64 n + 32 with only the last segment odd (the 96 -> 32 and 32 -> 64 blocks: K = 480, 160): 64-wide chunks with a
+      // half-empty last one (KTAIL) instead of 32-wide ones
+      bool tail = !k64 && g_force_bk != 32 && a.K > 64 && a.seg[a.nseg - 1].ch % 64 == 32;
+      for (int i = 0; i + 1 < a.nseg; ++i) tail = tail && (a.seg[i].ch % 64 == 0);
+      if (tail) return BN == 64 ? launch_cfg<T, 128, 64, 2, 2, 64, false, true>(a, s) : launch_cfg<T, 128, 32, 4, 1, 64, false, true>(a, s);
+    }
     if (BN == 64) return k64 ? launch_cfg<T, 128, 64, 2, 2, 64>(a, s) : launch_cfg<T, 128, 64, 2, 2, 32>(a, s);
     return k64 ? launch_cfg<T, 128, 32, 4, 1, 64>(a, s) : launch_cfg<T, 128, 32, 4, 1, 32>(a, s);
   }
