@@ -145,9 +145,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[B
 
 // STAMP: diagnostic build (llie_tune("gemm_stamp", 1)): s_memtime per wave at kernel start / after the K loop / at the end,
 // summed into g.stamps[0..2] = {K loop, epilogue, waves}; never used in production.
-// KTAIL (BK = 64 only): K = 64 n + 32 -- the last chunk's upper 32 columns do not exist and are staged as zeros (A and W), so the
-// 96 -> 32 project GEMM (K = 384 + 64 + 32) runs with 64-wide chunks like its 128 -> 32 sibling instead of 32-wide ones (half the
-// bytes per barrier: 4.4 instead of 5.6 TB/s).  The sequence of 32-wide k-steps per accumulator, hence every bit, is unchanged.
+// KTAIL (BK = 64 only): K segments of 64 n + 32 channels -- chunks never straddle a segment: the last chunk of such a segment has
+// no upper 32 columns and stages zeros there (A and W), so the 96 -> 32 project GEMM (K = 384 + 64 + 32) and `base`'s 48 / 96 / 144-
+// channel shapes run with 64-wide chunks like their even siblings instead of 32-wide ones (half the barriers per byte: 4.4 -> 4.8
+// TB/s on the former).  An all-zero 32-wide k-step adds +0 to every accumulator and the others keep their order: same bits.
 template <typename T, int BM, int BN, int WM, int WN, int BK, bool STAMP = false, bool RAGGED = false, bool KTAIL = false>
 __global__ void __launch_bounds__(WM* WN * 64) pw_gemm_kernel(const GemmArgs g) {
   static_assert(!RAGGED || BM == 64, "ragged images use the 64-row tiles");
@@ -203,12 +204,22 @@ __global__ void __launch_bounds__(WM* WN * 64) pw_gemm_kernel(const GemmArgs g) 
   const int koff1 = g.seg[0].ch, koff2 = g.seg[0].ch + g.seg[1].ch;
   const T* wbase = reinterpret_cast<const T*>(g.w);
 
+  int t_seg = 0, t_cl = 0, t_koff = 0;  // KTAIL: segment of the next chunk, its offset inside the segment, the segment's first k
   auto prefetch = [&](int k0) {
-    const int s = (g.nseg > 1 && k0 >= koff1) + (g.nseg > 2 && k0 >= koff2);
+    const int s = KTAIL ? t_seg : (g.nseg > 1 && k0 >= koff1) + (g.nseg > 2 && k0 >= koff2);
     const GemmSeg sg = g.seg[s];
-    const int cl = k0 - (s == 0 ? 0 : (s == 1 ? koff1 : koff2));
+    const int cl = KTAIL ? t_cl : k0 - (s == 0 ? 0 : (s == 1 ? koff1 : koff2));
+    if constexpr (KTAIL) k0 = t_koff + t_cl;  // W column of the chunk's first k
     const T* abase = reinterpret_cast<const T*>(sg.ptr);
-    const bool kval = !KTAIL || k0 + kv < g.K;  // this thread's 16-byte column slice exists
+    const bool kval = !KTAIL || cl + kv < sg.ch;  // this thread's 16-byte column slice exists
+    if constexpr (KTAIL) {
+      t_cl += BK;
+      if (t_cl >= sg.ch) {
+        t_koff += sg.ch;
+        t_cl = 0;
+        ++t_seg;
+      }
+    }
 #pragma unroll
     for (int i = 0; i < A_PER; ++i) {
       const int idx = tid + i * NT;
@@ -298,7 +309,11 @@ __global__ void __launch_bounds__(WM* WN * 64) pw_gemm_kernel(const GemmArgs g) 
     }
   };
 
-  const int nchunks = (g.K + BK - 1) / BK;
+  int nchunks = g.K / BK;
+  if constexpr (KTAIL) {
+    nchunks = 0;
+    for (int i = 0; i < g.nseg; ++i) nchunks += (g.seg[i].ch + BK - 1) / BK;
+  }
   prefetch(0);
   for (int c = 0; c < nchunks; ++c) {
     if (!(g.dbg & 2) || c == 0) stage();  // dbg bit 1: timing ablation (no re-staging)
@@ -426,14 +441,16 @@ static hipError_t launch_t(const GemmArgs& a, hipStream_t s) {
     }
   }
   if (BM == 128) {
-    if (BN == 128) return k64 ? launch_cfg<T, 128, 128, 2, 2, 64>(a, s) : launch_cfg<T, 128, 128, 2, 2, 32>(a, s);
     if constexpr (sizeof(T) == 2) {
-      // K = 64 n + 32 with only the last segment odd (the 96 -> 32 and 32 -> 64 blocks: K = 480, 160): 64-wide chunks with a
-      // half-empty last one (KTAIL) instead of 32-wide ones
-      bool tail = !k64 && g_force_bk != 32 && a.K > 64 && a.seg[a.nseg - 1].ch % 64 == 32;
-      for (int i = 0; i + 1 < a.nseg; ++i) tail = tail && (a.seg[i].ch % 64 == 0);
-      if (tail) return BN == 64 ? launch_cfg<T, 128, 64, 2, 2, 64, false, true>(a, s) : launch_cfg<T, 128, 32, 4, 1, 64, false, true>(a, s);
+      // some segment has 64 n + 32 channels (the 96 -> 32 and 32 -> 64 blocks: K = 480, 160; `base`'s 48 / 96 / 144-channel shapes):
+      // 64-wide chunks with half-empty segment tails (KTAIL) instead of 32-wide ones
+      if (!k64 && g_force_bk != 32 && a.K > 64) {
+        if (BN == 128) return launch_cfg<T, 128, 128, 2, 2, 64, false, true>(a, s);
+        if (BN == 64) return launch_cfg<T, 128, 64, 2, 2, 64, false, true>(a, s);
+        return launch_cfg<T, 128, 32, 4, 1, 64, false, true>(a, s);
+      }
     }
+    if (BN == 128) return k64 ? launch_cfg<T, 128, 128, 2, 2, 64>(a, s) : launch_cfg<T, 128, 128, 2, 2, 32>(a, s);
     if (BN == 64) return k64 ? launch_cfg<T, 128, 64, 2, 2, 64>(a, s) : launch_cfg<T, 128, 64, 2, 2, 32>(a, s);
     return k64 ? launch_cfg<T, 128, 32, 4, 1, 64>(a, s) : launch_cfg<T, 128, 32, 4, 1, 32>(a, s);
   }

@@ -172,3 +172,48 @@ def test_se_mlp_on_the_matrix_pipe(dev, cd, tol, cin, cout, hw, b):
     assert (y1 - ref).abs().max().item() < tol * scale, (y1 - ref).abs().max().item() / scale
     assert (y1 - y0).abs().max().item() < tol * scale
     assert torch.equal(one[0], y1[0]) and torch.equal(again, y1)
+
+
+# ------------------------------------------------------------------ K segments of 64 n + 32 channels in the tile GEMM
+@pytest.mark.parametrize("dtype,tdt,ulp", [(1, torch.float16, 2.0 ** -10), (2, torch.bfloat16, 2.0 ** -7)])
+@pytest.mark.parametrize("segs,nout", [([384, 64, 32], 32), ([128, 32], 64), ([96, 64, 32], 128), ([32, 96], 64), ([96, 96, 160], 32), ([160], 128),
+                                       ([96], 32)])
+def test_pw_gemm_half_empty_segment_tails(dev, dtype, tdt, ulp, segs, nout):
+    """1x1 conv over a virtual concat (efficient_unet.py:186,199,265-267) whose segments are not all multiples of 64 channels
+    (the 96 -> 32 and 32 -> 64 blocks of `small`, `base`'s 48 / 96 / 144-channel shapes): 64-wide K chunks with half-empty segment
+    tails against float64, and bit for bit against the 32-wide chunks they replace (knob "gemm_bk" = 32)."""
+    L = N.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    B, P, K = 2, 256, sum(segs)
+    g = torch.Generator().manual_seed(K * 7 + nout)
+    xs = [(torch.randn(B * P, c, generator=g) * 1.5).to(tdt) for c in segs]
+    w32 = torch.randn(nout, K, generator=g) / math.sqrt(K)
+    sc = (torch.rand(B, K, generator=g) + 0.5) / 6
+    bi = (torch.randn(B, K, generator=g) * 0.5 + 0.4) / 6
+    xd = [x.to(dev) for x in xs]
+    scd, bid, wt = sc.to(dev), bi.to(dev), w32.to(dev).to(tdt)
+    arr = (N.GemmSeg * len(xs))()
+    off = 0
+    for i, x in enumerate(xd):
+        arr[i] = N.GemmSeg(x.data_ptr(), x.shape[1], scd.data_ptr() + off * 4, bid.data_ptr() + off * 4, K, 3)
+        off += x.shape[1]
+    outs = []
+    try:
+        for bk in (0, 32):
+            N.check(L.llie_tune(b"gemm_bk", bk))
+            out = torch.full((B * P, nout), float("nan"), dtype=tdt, device=dev)
+            stats = torch.full((B, P // 128, 2, nout), float("nan"), device=dev)
+            N.check(L.llie_pw_gemm(dtype, arr, len(xs), wt.data_ptr(), None, None, out.data_ptr(), stats.data_ptr(), B * P, nout, P, st), "pw_gemm")
+            torch.cuda.synchronize()
+            outs.append((out.cpu(), stats.cpu()))
+    finally:
+        L.llie_tune(b"gemm_bk", 0)
+    (out, stats), (out32, stats32) = outs
+    assert torch.isfinite(out.float()).all() and torch.isfinite(stats).all()
+    assert torch.equal(out, out32) and torch.equal(stats, stats32)
+    x = torch.cat([v.float() for v in xs], 1).view(B, P, -1)
+    a = (x.double() * sc[:, None, :].double() + bi[:, None, :].double()).clamp(0, 1).to(tdt).double()
+    ref = 6.0 * (a @ wt.cpu().double().t()).view(B * P, nout)
+    err = (out.double() - ref).abs()
+    tol = ulp * ref.abs() + ulp * 2.5
+    assert (err <= tol).all(), (err / tol).max().item()
