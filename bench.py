@@ -202,19 +202,28 @@ def train_bench(args, M, dev, rank: int, world: int) -> None:
     low = (torch.rand(B, 3, S, S, generator=g) * 2 - 1).to(dev)
     normal = (torch.rand(B, 3, S, S, generator=g) * 2 - 1).to(dev)
     params = list(model.parameters())
-    opt = torch.optim.AdamW(params, lr=1e-4, weight_decay=0.01, fused=True)
-    ema = [p.detach().clone() for p in params]
+    if args.train_autograd:
+        # the reference trainer's own calls on top of the engine's autograd node (any torch optimiser works this way)
+        opt = torch.optim.AdamW(params, lr=1e-4, weight_decay=0.01, fused=True)
+        ema = [p.detach().clone() for p in params]
 
-    def step():
-        opt.zero_grad(set_to_none=True)
-        loss = model.compute_loss(low, normal, loss_type="mse", use_velocity_target=True)
-        loss.backward()
-        M.all_reduce_gradients(params)
-        torch.nn.utils.clip_grad_norm_(params, 1.0)
-        opt.step()
-        torch._foreach_mul_(ema, 0.9999)
-        torch._foreach_add_(ema, [p.detach() for p in params], alpha=1 - 0.9999)
-        return loss
+        def step():
+            opt.zero_grad(set_to_none=True)
+            loss = model.compute_loss(low, normal, loss_type="mse", use_velocity_target=True)
+            loss.backward()
+            M.all_reduce_gradients(params)
+            torch.nn.utils.clip_grad_norm_(params, 1.0)
+            opt.step()
+            torch._foreach_mul_(ema, 0.9999)
+            torch._foreach_add_(ema, [p.detach() for p in params], alpha=1 - 0.9999)
+            return loss
+    else:
+        # the same arithmetic without the autograd graph: flat gradients, one all-reduce, clip + AdamW + EMA in three launches
+        opt = M.FusedAdamW(params, lr=1e-4, weight_decay=0.01, max_grad_norm=1.0, ema_decay=0.9999)
+        train_step = M.TrainStep(model, opt, loss_type="mse", use_velocity_target=True)
+
+        def step():
+            return train_step(low, normal)
 
     log(f"training model built on {dev}; warm-up x{args.warmup}")
     for _ in range(args.warmup):
@@ -274,6 +283,9 @@ def main() -> None:
     ap.add_argument("--dtype", default="fp16", choices=["fp32", "fp16", "bf16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--train-autograd", dest="train_autograd", action="store_true",
+                    help="with --train: loss.backward() + clip_grad_norm_ + torch.optim.AdamW + foreach EMA on the engine's autograd "
+                         "node instead of TrainStep / FusedAdamW (same arithmetic)")
     ap.add_argument("--train", action="store_true",
                     help="time the training step instead (BASELINE config 5; not the headline line): compute_loss -> "
                          "backward -> gradient all-reduce -> clip -> AdamW -> EMA, as src/training/trainer.py:281-338")

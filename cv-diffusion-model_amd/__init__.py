@@ -13,6 +13,7 @@ from .unet import (EfficientUNet, EfficientUNetConfig, create_efficient_unet, In
 from .scheduler import LCMScheduler, LCMSchedulerOutput, LCMDenoisingLoop, get_lcm_timesteps
 from .pipeline import LowLightDiffusion, LowLightDiffusionOutput, normalize_image, denormalize_image
 from .sharding import shard_range, enhance_sharded, all_gather_batch, all_reduce_gradients
+from .training import FusedAdamW, TrainStep
 from .build import build_library, library_path
 from . import ops  # registers torch.ops.llie.*
 from .ops import register_model
@@ -23,6 +24,6 @@ __all__ = [
     "EfficientUNet", "EfficientUNetConfig", "create_efficient_unet", "InvertedResidualBlock", "LinearAttention", "SqueezeExcitation",
     "Downsample", "Upsample", "LCMScheduler", "LCMSchedulerOutput", "LCMDenoisingLoop", "get_lcm_timesteps", "LowLightDiffusion",
     "LowLightDiffusionOutput", "normalize_image", "denormalize_image", "shard_range", "enhance_sharded",
-    "all_gather_batch", "all_reduce_gradients", "register_model", "build_library", "library_path", "load_checkpoint", "extract_state_dict",
+    "all_gather_batch", "all_reduce_gradients", "FusedAdamW", "TrainStep", "register_model", "build_library", "library_path", "load_checkpoint", "extract_state_dict",
     "preprocess_array", "postprocess_array", "resize_bilinear", "preprocess_device", "postprocess_device",
 ]

@@ -26,6 +26,7 @@ EXPORTS = [
     "llie_preprocess_u8", "llie_postprocess_u8", "llie_profile_report", "llie_pw_gemm", "llie_pw_gemm_tile_rows", "llie_dwconv3x3", "llie_dwconv3x3_tiles", "llie_tune",
     "llie_grad_numel", "llie_param_grad_offset", "llie_train_workspace_bytes", "llie_unet_train_forward",
     "llie_unet_backward", "llie_module_backward", "llie_load_all", "llie_profile_dump", "llie_copy_probe", "llie_rw_probe", "llie_pw_expand", "llie_gram_stats", "llie_gram_part_floats", "llie_groupnorm_finalize", "llie_conv3x3", "llie_conv3x3_tiles", "llie_linattn", "llie_linattn_splits", "llie_se_mlp", "llie_film", "llie_refresh_params", "llie_path_bytes", "llie_time_embed", "llie_debug_irbx_stamps", "llie_debug_gemm_stamps", "llie_debug_pwx_stamps", "llie_graph_cache_entries", "llie_debug_conv_stamps", "llie_gram_finalize",
+    "llie_optimizer_create", "llie_optimizer_destroy", "llie_optimizer_numel", "llie_optimizer_step",
 ]
 K_GEMM, K_DW, K_CONV3, K_SE, K_OTHER = 1, 2, 4, 8, 16
 
@@ -46,6 +47,19 @@ class Config(C.Structure):
         ("expansion_ratio", C.c_int), ("time_embed_dim", C.c_int), ("num_attention_heads", C.c_int),
         ("image_size", C.c_int), ("attention_resolutions", C.c_int * 2), ("allow_unpinned", C.c_int),
     ]
+
+
+class OptTensor(C.Structure):
+    """llie_opt_tensor (include/llie.h): one parameter of the fused optimiser step."""
+    _fields_ = [("param", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p), ("ema", C.c_void_p),
+                ("grad_offset", C.c_int64), ("numel", C.c_int64)]
+
+
+class OptHyper(C.Structure):
+    """llie_opt_hyper (include/llie.h)."""
+    _fields_ = [("lr", C.c_double), ("beta1", C.c_double), ("beta2", C.c_double), ("eps", C.c_double), ("weight_decay", C.c_double),
+                ("max_grad_norm", C.c_double), ("ema_decay", C.c_double), ("grad_scale", C.c_double), ("step", C.c_int64),
+                ("skip_nonfinite", C.c_int32)]
 
 
 class StepCoef(C.Structure):
@@ -120,6 +134,12 @@ def lib() -> C.CDLL:
     L.llie_dwconv3x3_tiles.argtypes = [ci, ci]
     L.llie_tune.argtypes = [C.c_char_p, ci]
     L.llie_debug_irbx_stamps.argtypes = [C.POINTER(C.c_double)]
+    L.llie_optimizer_create.argtypes = [C.POINTER(OptTensor), ci, C.POINTER(C.c_void_p)]
+    L.llie_optimizer_destroy.argtypes = [C.c_void_p]
+    L.llie_optimizer_destroy.restype = None
+    L.llie_optimizer_numel.argtypes = [C.c_void_p]
+    L.llie_optimizer_numel.restype = C.c_int64
+    L.llie_optimizer_step.argtypes = [C.c_void_p, vp, C.POINTER(OptHyper), vp, vp]
     L.llie_graph_cache_entries.argtypes = [C.c_void_p]
     L.llie_graph_cache_entries.restype = C.c_int
     L.llie_debug_gemm_stamps.argtypes = [C.POINTER(C.c_double)]

@@ -2341,6 +2341,75 @@ int llie_time_embed(llie_ctx* c, const int64_t* t, int rows, float* emb, float* 
   return LLIE_OK;
 }
 
+// ---- optimiser step (training): one object per parameter set, tables resident on the device
+struct llie_optimizer {
+  int device = 0;
+  OptTensor* tensors = nullptr;
+  OptChunk* chunks = nullptr;
+  double* partial = nullptr;
+  int count = 0, nchunks = 0;
+  int64_t numel = 0;
+};
+
+int llie_optimizer_create(const llie_opt_tensor* tensors, int count, llie_optimizer** out) {
+  if (!tensors || count <= 0 || !out) return LLIE_ERR_ARG;
+  std::vector<OptTensor> tt((size_t)count);
+  std::vector<OptChunk> cc;
+  int64_t total = 0;
+  for (int i = 0; i < count; ++i) {
+    const llie_opt_tensor& t = tensors[i];
+    if (!t.param || !t.exp_avg || !t.exp_avg_sq || t.numel <= 0 || t.grad_offset < 0 || t.numel > (int64_t)INT32_MAX) {
+      set_err("optimizer_create: tensor %d: null pointer, empty tensor or negative gradient offset", i);
+      return LLIE_ERR_ARG;
+    }
+    tt[(size_t)i] = OptTensor{t.param, t.exp_avg, t.exp_avg_sq, t.ema, (long long)t.grad_offset, (long long)t.numel};
+    for (int64_t o = 0; o < t.numel; o += kOptChunk) cc.push_back(OptChunk{i, (int)o});
+    total += t.numel;
+  }
+  if (cc.size() > (size_t)INT32_MAX) return LLIE_ERR_ARG;
+  auto* o = new llie_optimizer();
+  o->count = count;
+  o->nchunks = (int)cc.size();
+  o->numel = total;
+  hipError_t e = hipGetDevice(&o->device);
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&o->tensors), tt.size() * sizeof(OptTensor));
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&o->chunks), cc.size() * sizeof(OptChunk));
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&o->partial), cc.size() * sizeof(double));
+  if (e == hipSuccess) e = hipMemcpy(o->tensors, tt.data(), tt.size() * sizeof(OptTensor), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(o->chunks, cc.data(), cc.size() * sizeof(OptChunk), hipMemcpyHostToDevice);
+  if (e != hipSuccess) {
+    set_err("optimizer_create: %s", hipGetErrorString(e));
+    llie_optimizer_destroy(o);
+    return e == hipErrorNoDevice ? LLIE_ERR_NO_DEVICE : (int)e;
+  }
+  *out = o;
+  return LLIE_OK;
+}
+
+void llie_optimizer_destroy(llie_optimizer* o) {
+  if (!o) return;
+  if (o->tensors) (void)hipFree(o->tensors);
+  if (o->chunks) (void)hipFree(o->chunks);
+  if (o->partial) (void)hipFree(o->partial);
+  delete o;
+}
+
+int64_t llie_optimizer_numel(const llie_optimizer* o) { return o ? o->numel : (int64_t)LLIE_ERR_ARG; }
+
+int llie_optimizer_step(llie_optimizer* o, const float* grad_base, const llie_opt_hyper* h, float* stats3, llie_stream stream) {
+  if (!o || !grad_base || !h || !stats3) return LLIE_ERR_ARG;
+  OptStepArgs a{};
+  a.tensors = o->tensors; a.chunks = o->chunks; a.nchunks = o->nchunks;
+  a.gbase = grad_base; a.partial = o->partial; a.stats = stats3;
+  a.lr = h->lr; a.beta1 = h->beta1; a.beta2 = h->beta2; a.eps = h->eps; a.weight_decay = h->weight_decay;
+  a.max_grad_norm = h->max_grad_norm; a.ema_decay = h->ema_decay; a.grad_scale = h->grad_scale;
+  a.step = h->step; a.skip_nonfinite = h->skip_nonfinite;
+  hipError_t e = launch_optimizer_step(a, reinterpret_cast<hipStream_t>(stream));
+  if (e == hipErrorInvalidValue) { set_err("optimizer_step: hyper-parameters outside their ranges (lr, eps, weight_decay >= 0; 0 <= beta < 1; ema_decay <= 1; step >= 1)"); return LLIE_ERR_ARG; }
+  if (e != hipSuccess) { set_err("optimizer_step: %s", hipGetErrorString(e)); return (int)e; }
+  return LLIE_OK;
+}
+
 int llie_copy_probe(const void* src, void* dst, int64_t bytes, llie_stream stream) {
   if (!src || !dst || bytes <= 0) return LLIE_ERR_ARG;
   hipError_t e = launch_copy_probe(src, dst, bytes, reinterpret_cast<hipStream_t>(stream));

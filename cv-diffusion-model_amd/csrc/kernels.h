@@ -480,4 +480,22 @@ struct AttnBwdArgs {
 hipError_t launch_linattn_bwd_q(int dtype, const AttnBwdArgs& a, hipStream_t s);
 hipError_t launch_linattn_bwd_kv(int dtype, const AttnBwdArgs& a, hipStream_t s);
 
+// (9) optimiser step over all parameter tensors (optim.hip): gradient norm -> clip coefficient -> AdamW (+ EMA shadow)
+constexpr int kOptChunk = 4096;  // elements per workgroup
+struct OptTensor { float* p; float* m; float* v; float* ema; long long goff; long long n; };  // goff: element offset of the gradient in the flat buffer
+struct OptChunk { int tensor; int first; };                                                    // first element of the run inside the tensor
+struct OptStepArgs {
+  const OptTensor* tensors; const OptChunk* chunks; int nchunks;  // device tables
+  const float* gbase;                                              // flat fp32 gradients
+  double* partial;                                                 // [nchunks] scratch
+  float* stats;                                                    // [3]: ||g||, factor applied to g, 1 = step skipped
+  double lr, beta1, beta2, eps, weight_decay;
+  double max_grad_norm;  // <= 0: no clipping
+  double ema_decay;      // < 0: no EMA update
+  double grad_scale;     // multiplies every gradient first (1 / loss scale, 1 / world size)
+  long long step;        // 1-based step count (bias correction)
+  int skip_nonfinite;    // leave everything untouched when the norm is inf / NaN (GradScaler.step)
+};
+hipError_t launch_optimizer_step(const OptStepArgs& a, hipStream_t s);
+
 }  // namespace llie

@@ -161,6 +161,38 @@ int llie_unet_backward(llie_ctx* ctx, const float* d_eps, float* grads, int batc
 int llie_module_backward(llie_ctx* ctx, const float* x, const float* temb, const float* dy, float* dx, float* dtemb,
                          float* grads, int batch, int H, int W, void* workspace, int64_t workspace_bytes, llie_stream stream);
 
+/* ---- Optimiser step of the training loop (replaces, in the trainer's inner loop src/training/trainer.py:296-324, the eager
+ * sequence  scaler.unscale_ -> torch.nn.utils.clip_grad_norm_(params, gradient_clip) -> optimizer.step() [torch.optim.AdamW,
+ * trainer.py:163-168] -> EMAModel.update (trainer.py:98-104)  by three launches over every parameter tensor at once; same
+ * arithmetic operation for operation: decoupled decay p *= 1 - lr wd; m = m + (g - m)(1 - b1); v = b2 v + (1 - b2) g g;
+ * p -= lr / (1 - b1^t) * m / (sqrt(v) / sqrt(1 - b2^t) + eps); shadow = decay shadow + (1 - decay) p).
+ * A tensor's gradient is read at grad_base + grad_offset (the flat buffer llie_unet_backward fills: grad_offset =
+ * llie_param_grad_offset(i)); `ema` may be NULL.  All pointers are device fp32 and must stay valid for the optimiser's life.
+ * llie_optimizer_step: every gradient is first multiplied by grad_scale (1 / loss scale, 1 / world size); the total norm of the
+ * scaled gradients is clipped to max_grad_norm (<= 0: no clipping) as clip_grad_norm_ does (factor min(1, max / (norm + 1e-6)));
+ * ema_decay < 0: shadows untouched; skip_nonfinite != 0: a non-finite norm leaves parameters, moments and shadows unchanged
+ * (GradScaler.step).  `step` is the 1-based count of this update.  stats3 (device, 3 floats) receives {gradient norm, factor
+ * applied to the gradients, 1 if the step was skipped else 0}.  The norm is a fixed-order sum: bitwise reproducible. */
+typedef struct llie_opt_tensor {
+  float* param;
+  float* exp_avg;
+  float* exp_avg_sq;
+  float* ema;
+  int64_t grad_offset; /* elements */
+  int64_t numel;
+} llie_opt_tensor;
+typedef struct llie_opt_hyper {
+  double lr, beta1, beta2, eps, weight_decay;
+  double max_grad_norm, ema_decay, grad_scale;
+  int64_t step;
+  int32_t skip_nonfinite;
+} llie_opt_hyper;
+typedef struct llie_optimizer llie_optimizer;
+int llie_optimizer_create(const llie_opt_tensor* tensors /* host array */, int count, llie_optimizer** out);
+void llie_optimizer_destroy(llie_optimizer* opt);
+int64_t llie_optimizer_numel(const llie_optimizer* opt);
+int llie_optimizer_step(llie_optimizer* opt, const float* grad_base, const llie_opt_hyper* hyper, float* stats3, llie_stream stream);
+
 /* LCMScheduler.step (lcm_scheduler.py:176-253), elementwise on fp32 [n]:
  *   x0 = (sample - sqrt_beta_t*model_output)/sqrt_alpha_t      (epsilon)
  *   prev = is_last ? x0 : sqrt_alpha_prev*x0 + sqrt_beta_prev*noise

@@ -217,3 +217,170 @@ def test_pw_gemm_half_empty_segment_tails(dev, dtype, tdt, ulp, segs, nout):
     err = (out.double() - ref).abs()
     tol = ulp * ref.abs() + ulp * 2.5
     assert (err <= tol).all(), (err / tol).max().item()
+
+
+# ------------------------------------------------------------------ optimiser step: clip + AdamW + EMA in three launches
+_OPT_SHAPES = [(3,), (32,), (5, 7), (128, 64, 1, 1), (4097,), (3, 32, 3, 3), (1,), (8192,), (300, 41), (512, 9)]
+
+
+def _opt_case(dev, seed):
+    g = torch.Generator().manual_seed(seed)
+    ps = [torch.nn.Parameter((torch.randn(*s, generator=g) * 0.3).to(dev)) for s in _OPT_SHAPES]
+    qs = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+    return g, ps, qs
+
+
+def _torch_reference_step(qs, ema, opt, max_norm, decay):
+    norm = torch.nn.utils.clip_grad_norm_(qs, max_norm) if max_norm else None   # trainer.py:310-313
+    opt.step()                                                                  # trainer.py:315
+    for e, q in zip(ema, qs):                                                   # EMAModel.update, trainer.py:98-104
+        e.mul_(decay).add_(q.data, alpha=1 - decay)
+    return norm
+
+
+@pytest.mark.parametrize("flat", [False, True])
+def test_fused_adamw_matches_clip_grad_norm_adamw_and_ema(dev, flat):
+    """FusedAdamW (llie_optimizer_step) against torch.nn.utils.clip_grad_norm_ + torch.optim.AdamW + the reference's EMA update
+    over five steps: gradients in separate allocations (`step()`) and in one flat buffer with gaps (`step_flat`), the clip active
+    in some steps and not in others.  fp32 on both sides, same operation order: a few units in the last place."""
+    g, ps, qs = _opt_case(dev, 11)
+    kw = dict(lr=3e-3, betas=(0.9, 0.99), eps=1e-8, weight_decay=0.05)
+    fused = M.FusedAdamW(ps, **kw, max_grad_norm=1.0, ema_decay=0.99)
+    ref = torch.optim.AdamW(qs, **kw, foreach=False, fused=False)
+    ema = [q.detach().clone() for q in qs]
+    numel = [p.numel() for p in ps]
+    offs, o = [], 5
+    for n in numel:  # odd gaps: most gradients are not 16-byte aligned
+        offs.append(o)
+        o += n + 3
+    for it in range(5):
+        amp = [0.01, 3.0, 0.002, 10.0, 0.3][it]
+        gs = [torch.randn(*s, generator=g).to(dev) * amp for s in _OPT_SHAPES]
+        for q, gr in zip(qs, gs):
+            q.grad = gr.clone()
+        norm_ref = _torch_reference_step(qs, ema, ref, 1.0, 0.99)
+        if flat:
+            buf = torch.full((o,), float("nan"), device=dev)
+            for gr, off, n in zip(gs, offs, numel):
+                buf[off:off + n] = gr.reshape(-1)
+            norm = fused.step_flat(buf, offs)
+        else:
+            for p, gr in zip(ps, gs):
+                p.grad = gr.clone()
+            fused.step()
+            norm = fused.grad_norm()
+        assert abs(norm.item() - norm_ref.item()) <= 2e-6 * norm_ref.item(), (it, norm.item(), norm_ref.item())
+        for i, (p, q) in enumerate(zip(ps, qs)):
+            assert torch.allclose(p, q, rtol=2e-6, atol=1e-7), (it, i, (p - q).abs().max().item())
+            st, sr = fused.state[p], ref.state[q]
+            assert torch.allclose(st["exp_avg"], sr["exp_avg"], rtol=2e-6, atol=1e-9), (it, i)
+            assert torch.allclose(st["exp_avg_sq"], sr["exp_avg_sq"], rtol=2e-6, atol=1e-12), (it, i)
+        for e, er in zip(fused.ema_tensors(), ema):
+            assert torch.allclose(e, er, rtol=2e-6, atol=1e-7), it
+    assert not fused.last_step_skipped()
+
+
+def test_fused_adamw_skips_a_nonfinite_step_and_keeps_torch_checkpoint_layout(dev):
+    """skip_nonfinite (GradScaler.step's rule): an inf gradient leaves parameters, moments and shadows untouched and does not
+    count as a step for nothing else either way; state_dict() loads into torch.optim.AdamW (the trainer's checkpoint layout,
+    trainer.py:418-434) and back, and both continue identically; an LR scheduler drives param_groups[0]['lr']."""
+    g, ps, qs = _opt_case(dev, 5)
+    kw = dict(lr=1e-2, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01)
+    fused = M.FusedAdamW(ps, **kw, max_grad_norm=0.5, ema_decay=0.9, skip_nonfinite=True)
+    sched = torch.optim.lr_scheduler.CosineAnnealingLR(fused, T_max=10, eta_min=1e-4)
+    ref = torch.optim.AdamW(qs, **kw, foreach=False, fused=False)
+    sched_ref = torch.optim.lr_scheduler.CosineAnnealingLR(ref, T_max=10, eta_min=1e-4)
+    for it in range(3):
+        for p, q in zip(ps, qs):
+            gr = torch.randn(p.shape, generator=g).to(dev)
+            p.grad, q.grad = gr.clone(), gr.clone()
+        torch.nn.utils.clip_grad_norm_(qs, 0.5)
+        ref.step(); sched_ref.step()
+        fused.step(); sched.step()
+    assert abs(fused.param_groups[0]["lr"] - ref.param_groups[0]["lr"]) < 1e-12
+    for p, q in zip(ps, qs):
+        assert torch.allclose(p, q, rtol=2e-6, atol=1e-7)
+    before = [p.detach().clone() for p in ps] + [fused._m.clone(), fused._v.clone(), fused._ema.clone()]
+    for p in ps:
+        p.grad = torch.randn(p.shape, generator=g).to(dev)
+    ps[3].grad[0, 0, 0, 0] = float("inf")
+    fused.step()
+    assert fused.last_step_skipped() and not math.isfinite(fused.grad_norm().item())
+    after = [p.detach().clone() for p in ps] + [fused._m, fused._v, fused._ema]
+    assert all(torch.equal(a, b) for a, b in zip(before, after))
+    # checkpoint: ours -> torch.optim.AdamW -> one more step on both
+    import copy
+    sd = copy.deepcopy(fused.state_dict())  # as torch.save / torch.load would (state_dict() hands out references, like torch's)
+    ema_flat = sd.pop("ema_shadow_flat")
+    assert ema_flat.numel() == sum(p.numel() for p in ps)
+    rs = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+    other = torch.optim.AdamW(rs, **kw, foreach=False, fused=False)
+    for st in sd["state"].values():  # the skipped update is no step of torch's either
+        st["step"] = torch.tensor(3.0)
+    other.load_state_dict(sd)
+    fused._step = 3
+    fused.skip_nonfinite = False
+    other.param_groups[0]["lr"] = fused.param_groups[0]["lr"]
+    for p, r in zip(ps, rs):
+        gr = torch.randn(p.shape, generator=g).to(dev) * 0.1
+        p.grad, r.grad = gr.clone(), gr.clone()
+    torch.nn.utils.clip_grad_norm_(rs, 0.5)
+    other.step()
+    fused.step()
+    for p, r in zip(ps, rs):
+        assert torch.allclose(p, r, rtol=2e-6, atol=1e-7)
+    # ... and torch's state_dict back into a fresh FusedAdamW
+    again = M.FusedAdamW([torch.nn.Parameter(p.detach().clone()) for p in ps], **kw)
+    again.load_state_dict(copy.deepcopy(other.state_dict()))
+    assert again._step == 4
+    assert torch.allclose(again._m, fused._m, rtol=2e-6, atol=1e-9) and torch.allclose(again._v, fused._v, rtol=2e-6, atol=1e-12)
+
+
+@pytest.mark.parametrize("cd", ["bf16", "fp32"])
+def test_train_step_matches_the_autograd_path(dev, cd):
+    """TrainStep (flat gradients, FusedAdamW) against compute_loss -> loss.backward() -> clip_grad_norm_ -> torch.optim.AdamW ->
+    EMA on the engine's autograd node (trainer.py:281-324), small@64, B=2, same random draws: the same loss and the same
+    gradients bit for bit, parameters and shadows equal to optimiser rounding after the step.  (Only one step is compared: at
+    initialisation a 3e-7 difference in the parameters moves the next step's gradient norm by 6e-5 in fp32 and by 10 % in bf16.)
+    Then two more steps, after which the engine must be running on the updated parameters: its output equals that of a fresh
+    model loaded from state_dict() -- the optimiser writes the fp32 masters behind PyTorch's version counters."""
+    import copy
+    sched = M.LCMScheduler(num_train_timesteps=1000, beta_schedule="scaled_linear", prediction_type="v_prediction", rescale_betas_zero_snr=True)
+    torch.manual_seed(3)
+    a = M.LowLightDiffusion(unet_variant="small", image_size=64, compute_dtype=cd, scheduler=sched).to(dev).train()
+    b = copy.deepcopy(a)
+    low = synth_input("r4:tlow", (2, 3, 64, 64), -1.0, -0.2).to(dev)
+    normal = synth_input("r4:tnormal", (2, 3, 64, 64), -1.0, 1.0).to(dev)
+    pa, pb = list(a.parameters()), list(b.parameters())
+    kw = dict(lr=1e-3, weight_decay=0.01)
+    opt_a = torch.optim.AdamW(pa, **kw, foreach=False, fused=False)
+    ema_a = [p.detach().clone() for p in pa]
+    opt_b = M.FusedAdamW(pb, **kw, max_grad_norm=1.0, ema_decay=0.999)
+    step_b = M.TrainStep(b, opt_b, loss_type="mse", use_velocity_target=True)
+    torch.manual_seed(100)
+    la = a.compute_loss(low, normal, loss_type="mse", use_velocity_target=True)
+    la.backward()
+    ga = [p.grad.detach().clone() for p in pa]
+    norm_a = _torch_reference_step(pa, ema_a, opt_a, 1.0, 0.999)
+    torch.manual_seed(100)
+    lb = step_b(low, normal)
+    assert torch.equal(la.detach(), lb), (la.item(), lb.item())
+    for g_ref, off, p in zip(ga, step_b._offsets, pb):
+        assert torch.equal(step_b._flat[off:off + p.numel()].view_as(p), g_ref)
+    assert abs(opt_b.grad_norm().item() - norm_a.item()) <= 2e-6 * norm_a.item()
+    for x, y in zip(pb, pa):
+        assert torch.allclose(x, y, rtol=2e-6, atol=2e-9), (x - y).abs().max().item()
+    for e, er in zip(opt_b.ema_tensors(), ema_a):
+        assert torch.allclose(e, er, rtol=2e-6, atol=2e-9)
+    losses = [step_b(low, normal).item() for _ in range(2)]
+    assert all(math.isfinite(v) for v in losses)
+    fresh = M.LowLightDiffusion(unet_variant="small", image_size=64, compute_dtype=cd, scheduler=sched)
+    fresh.load_state_dict(b.state_dict())
+    fresh = fresh.to(dev).eval()
+    b.eval()
+    t = torch.tensor([500, 20], device=dev)
+    with torch.no_grad():
+        x = torch.cat([normal, low], 1)
+        assert torch.equal(b.unet(x, t), fresh.unet(x, t))
+    with pytest.raises(ValueError):
+        M.TrainStep(b, M.FusedAdamW(pb[:-1], **kw))

@@ -470,3 +470,32 @@ def test_groupnorm_finalize_rejects_bad_arguments_before_touching_the_device():
         return L.llie_groupnorm_finalize(p, ntiles0, ch0, slab1, ntiles1, ch1, groups, pixels, p, p, None, 0, 1e-5, 0.0, 1, p, p, None)
     for kw in (dict(groups=0), dict(groups=-4), dict(pixels=0), dict(ntiles0=0), dict(ch0=48), dict(slab1=p, ch1=32, ntiles1=0), dict(ch0=0)):
         assert call(**kw) < 0, kw
+
+
+def test_optimizer_entry_points_reject_bad_arguments_without_a_device():
+    """llie_optimizer_create / _step (include/llie.h): null tables, empty tensors and negative gradient offsets come back as
+    LLIE_ERR_ARG before any HIP call; FusedAdamW refuses CPU parameters (no CPU fallback) and more than one parameter group."""
+    import ctypes as C
+    L = native.lib()
+    out = C.c_void_p()
+    buf = (C.c_float * 16)()
+    p = C.cast(buf, C.c_void_p).value
+    assert L.llie_optimizer_create(None, 1, C.byref(out)) == native.ERR_ARG
+    arr = (native.OptTensor * 1)(native.OptTensor(p, p, p, None, 0, 0))
+    assert L.llie_optimizer_create(arr, 1, C.byref(out)) == native.ERR_ARG            # empty tensor
+    arr = (native.OptTensor * 1)(native.OptTensor(p, p, None, None, 0, 16))
+    assert L.llie_optimizer_create(arr, 1, C.byref(out)) == native.ERR_ARG            # no second moment
+    arr = (native.OptTensor * 1)(native.OptTensor(p, p, p, None, -4, 16))
+    assert L.llie_optimizer_create(arr, 1, C.byref(out)) == native.ERR_ARG            # negative gradient offset
+    assert L.llie_optimizer_create(arr, 0, C.byref(out)) == native.ERR_ARG
+    h = native.OptHyper(1e-3, 0.9, 0.999, 1e-8, 0.01, 1.0, 0.999, 1.0, 1, 0)
+    assert L.llie_optimizer_step(None, p, C.byref(h), p, None) == native.ERR_ARG
+    assert L.llie_optimizer_numel(None) < 0
+    L.llie_optimizer_destroy(None)
+    w = torch.nn.Parameter(torch.zeros(4))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        M.FusedAdamW([w])
+    with pytest.raises(ValueError):
+        M.FusedAdamW([{"params": [w]}, {"params": [torch.nn.Parameter(torch.zeros(2))]}])
+    with pytest.raises(ValueError):
+        M.FusedAdamW([w], betas=(1.0, 0.999))
