@@ -384,3 +384,4 @@ def test_train_step_matches_the_autograd_path(dev, cd):
         assert torch.equal(b.unet(x, t), fresh.unet(x, t))
     with pytest.raises(ValueError):
         M.TrainStep(b, M.FusedAdamW(pb[:-1], **kw))
+
