@@ -31,6 +31,7 @@ python -u bench.py --variant large --image_size 512 --batch 8 --dtype bf16 --no-
 python -u bench.py --variant base --lcm_steps 8 --batch 32 --no-cpu-baseline > $O/bench_base256_fp16_b32_n8.json 2>> $O/other.err
 python -u bench.py --train --batch 8 --dtype bf16 > $O/train_bf16_b8.json 2>> $O/other.err
 python -u bench.py --train --batch 32 --dtype bf16 --no-cpu-baseline > $O/train_bf16_b32.json 2>> $O/other.err
+python -u bench.py --train --train-autograd --batch 8 --dtype bf16 --no-cpu-baseline > $O/train_autograd_bf16_b8.json 2>> $O/other.err
 python -u tools/gpu_layers.py fp16 32 > $O/layers_fp16_b32.txt 2>&1
 python -u tools/gpu_layers.py fp16 1 > $O/layers_fp16_b1.txt 2>&1
 ls -la $O
