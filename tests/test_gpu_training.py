@@ -352,6 +352,7 @@ def test_data_parallel_gradients_two_ranks_one_gpu(dev):
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "gpu_ddp_check.py")], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
     assert r.stdout.count("1 all_reduce call(s)") == 2
+    assert r.stdout.count("ranks agree: True") == 2  # TrainStep + FusedAdamW on half batches == the full-batch step, same bits on both ranks
 
 
 def test_training_reduces_the_loss(dev):
