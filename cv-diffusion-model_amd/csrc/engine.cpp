@@ -672,6 +672,8 @@ struct Run {
     a.as = p<float>(as); a.ab = p<float>(ab); a.B = B; a.post_scale = post_scale;
     if (tape && rec) { a.mean_out = p<float>(mo); a.rstd_out = p<float>(ro); }
     if (g_skip_small & 1) return;
+    if ((g_skip_small & 4) && film && a.P <= 4096) return;          // bound on a producer-tail finalize behind pw_expand (norm2 + FiLM)
+    if ((g_skip_small & 8) && !film && !x1 && a.P <= 4096) return;  // ... behind project GEMMs / convs (norm1, single source)
     timed(LLIE_K_OTHER, (int64_t)B * C * 8, [&] { return launch_gn_finalize(a, s); }, "gn_finalize_kernel");
   }
 
