@@ -14,7 +14,8 @@
 
 There is no CPU fallback: both need the HIP library and parameters on a HIP device.
 """
-from typing import Dict, Iterable, List, Optional
+import ctypes as C
+from typing import Iterable, List, Optional
 
 import torch
 import torch.distributed as dist
@@ -73,7 +74,6 @@ class FusedAdamW(torch.optim.Optimizer):
             e = self._ema.data_ptr() + 4 * o if self._ema is not None else None
             arr[i] = N.OptTensor(p.data_ptr(), self._m.data_ptr() + 4 * o, self._v.data_ptr() + 4 * o, e, offsets[i], n)
             o += n
-        import ctypes as C
         out = C.c_void_p()
         with torch.cuda.device(self._dev):
             N.check(N.lib().llie_optimizer_create(arr, len(ps), C.byref(out)), "FusedAdamW")
@@ -99,7 +99,6 @@ class FusedAdamW(torch.optim.Optimizer):
                        float(self.max_grad_norm) if self.max_grad_norm else 0.0,
                        float(self.ema_decay) if self.ema_decay is not None else -1.0, float(grad_scale), self._step,
                        1 if self.skip_nonfinite else 0)
-        import ctypes as C
         with torch.cuda.device(self._dev):
             N.check(N.lib().llie_optimizer_step(self._native, grad_base, C.byref(h), self._stats.data_ptr(),
                                                 torch.cuda.current_stream(self._dev).cuda_stream), "FusedAdamW.step")
