@@ -674,6 +674,8 @@ struct Run {
     if (g_skip_small & 1) return;
     if ((g_skip_small & 4) && film && a.P <= 4096) return;          // bound on a producer-tail finalize behind pw_expand (norm2 + FiLM)
     if ((g_skip_small & 8) && !film && !x1 && a.P <= 4096) return;  // ... behind project GEMMs / convs (norm1, single source)
+    if ((g_skip_small & 16) && !film && !x1 && a.P >= 16384) return; // the single-source norm1 finalizes of the high-resolution levels
+    if ((g_skip_small & 32) && (film || x1) && a.P >= 16384) return; // the other high-resolution ones (norm2 + FiLM behind expand_stats / pw_expand, concat inputs)
     timed(LLIE_K_OTHER, (int64_t)B * C * 8, [&] { return launch_gn_finalize(a, s); }, "gn_finalize_kernel");
   }
 
