@@ -5,6 +5,10 @@
   * launch-policy knobs that must never change a bit: the cache policy of the big tensors' stores ("nt_mask" / "nt_min_mb"),
     expand_dw's grid ("irbx_grid*"): whole network, every compute dtype of the 2-byte engines
   * the hipGraph cache of llie_enhance is bounded (least recently used entry evicted) and an evicted key still gives its bits
+  * SqueezeExcitation MLP of the wide blocks on the matrix pipe (se_fc1_mfma / se_fc2_mfma) vs the oracle and the row-parallel pair
+  * llie_pw_gemm with K segments of 64 n + 32 channels: 64-wide chunks with half-empty segment tails, bit for bit the 32-wide chunks
+  * llie_optimizer_step (FusedAdamW: clip_grad_norm_ + AdamW + EMA in three launches) vs torch.optim.AdamW, skip of a non-finite
+    step, checkpoint layout in both directions, LR scheduler; TrainStep vs the autograd path
 """
 import importlib
 import math
